@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Mandelbrot tile escape-time path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--kernel default]
+
+One "step" = one pass of the hot path over one synthetic tile already described in HBM terms: the
+kernel generates its coordinates itself and writes int32 escape indices to a resident HBM buffer
+(nothing crosses PCIe inside the timed region).  Workload at every N: BASELINE.json configs[1]
+("cfg2"): 4096x4096 samples of the full set (centre -0.5+0i, span 3.0), max_iter (mrd) = 1000, fp64.
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); tiles are independent, so
+every rank computes its own tile with no data-path collective ("weak" scaling); the only
+communication is the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0.  `value` = whole-job G pixel-iterations/s where a pixel's iterations
+are count if count > 0 else mrd-1, summed from the kernel's own output.
+`roofline`: the path is bound by the fp64 vector-ALU issue rate (not HBM, not MFMA -- FMA contraction
+is forbidden by bit-exactness): achieved = 8 algorithmic flops per pixel-iteration / average kernel
+launch duration (HIP events on the launch stream); peak = CUs x 4 SIMD x 16 fp64 lanes x 2 flop x
+clock (78.6 TFLOP/s on MI355X).  Under parity the stream is 7 fp64 VALU ops per 8 flops, so the
+flops fraction cannot exceed 8/14 = 0.571; `valu_slot_util` (= 7 issue slots per pixel-iteration
+over the 39.3 T lane-op/s issue peak) is the "how close to the metal" figure.
+`cpu_baseline`: the strict-IEEE C oracle (oracle/, kind "port": the reference has no CPU
+implementation and its numba path cannot run here) on the host cores, rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+WORKLOADS = {
+    # name: (start_r, start_i, range, width, height, mrd, description)
+    "cfg1": (-2.0, -1.5, 3.0, 512, 512, 256, "512x512 full set (centre -0.5+0i, span 3.0), mrd 256"),
+    "cfg2": (-2.0, -1.5, 3.0, 4096, 4096, 1000, "4096x4096 full set (centre -0.5+0i, span 3.0), mrd 1000"),
+    "cfg3": (-0.743648, 0.131820, 1e-5, 8192, 8192, 10000,
+             "8192x8192 deep zoom (centre -0.743643+0.131825i, span 1e-5), mrd 10000"),
+    "chunk_l1": (-2.0, -2.0, 4.0, 4096, 4096, 1000, "DataChunk (level 1, 0, 0) = [-2,2]^2, mrd 1000"),
+}
+FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
+VALU_OPS_PER_PIXEL_ITER = 7     # 3 mul + 3 add + 1 fma(2, p, ci)  (contraction-free stream)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload):
+    """Time the C oracle (oracle/mandel_oracle.c, -ffp-contract=off) on the host cores."""
+    from oracle.oracle import COracle
+    sr, si, rng, w, h, mrd, _ = workload
+    o = COracle()
+    cores = o.max_threads()
+    # bounded sample: every `stride`-th row band of 8 rows, sized for roughly 10-30 CPU-seconds
+    stride = 1 if cores >= 4 else 4
+    bands = [(0, r, w, 8) for r in range(0, h, 8 * stride)]
+    t0 = time.perf_counter()
+    total = 0
+    if stride == 1:
+        _, _, total = o.view(sr, si, rng, rng, w, h, mrd, want_counts=False, want_bytes=False, nthreads=cores)
+        sample = f"the whole {w}x{h} tile, all rows"
+    else:
+        for win in bands:
+            total += o.view(sr, si, rng, rng, w, h, mrd, window=win, want_counts=False,
+                            want_bytes=False, nthreads=cores)[2]
+        sample = f"every {stride}th 8-row band of the {w}x{h} tile ({len(bands) * 8} rows)"
+    dt = time.perf_counter() - t0
+    return {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
+            "sample": sample + f", mrd {mrd}, C oracle gcc -O2 -ffp-contract=off, OpenMP dynamic rows",
+            "seconds": dt}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    fake = os.environ.get("MBK_BENCH_FAKE") == "1"   # CPU-only test hook for the N>1 control path
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+
+    import torch
+    import torch.distributed as dist
+
+    workload = WORKLOADS[args.workload]
+    sr, si, rng, width, height, mrd, desc = workload
+    npix = width * height
+
+    if world > 1:
+        if fake:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if fake:
+        dev = None
+        device_info = {"name": "fake", "compute_units": 256, "clock_mhz": 2400}
+
+        def launch():
+            time.sleep(0.001)
+
+        def sync():
+            pass
+    else:
+        from distributedmandelbrot_amd import MandelbrotDevice, View
+        torch.cuda.set_device(local_rank)
+        dev = MandelbrotDevice(local_rank)   # raises loudly without the HIP library / a gfx950 GPU
+        device_info = dev.info()
+        view = View(sr, si, rng, rng, width, height)
+        d_counts = torch.empty(npix, dtype=torch.int32, device=f"cuda:{local_rank}")
+        stream = torch.cuda.current_stream()
+
+        def launch():
+            dev.launch_view(view, mrd, d_counts=d_counts.data_ptr(), stream=stream.cuda_stream,
+                            kernel=args.kernel)
+
+        def sync():
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        launch()
+    sync()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if not fake:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            launch()
+            e1.record(stream)
+            events.append((e0, e1))
+        else:
+            launch()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if fake:
+        iters_per_step = 10 ** 9
+        kernel_ms = [elapsed / args.steps * 1e3] * args.steps
+        never = 0
+    else:
+        st = dev.reduce_counts(d_counts.data_ptr(), npix, mrd, stream=stream.cuda_stream)
+        iters_per_step, never = st.pixel_iterations, st.never_pixels
+        kernel_ms = [a.elapsed_time(b) for a, b in events]
+
+    # max elapsed over ranks, total work over ranks
+    if world > 1:
+        dev_t = "cpu" if fake else f"cuda:{local_rank}"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_max = float(t.item())
+        w_ = torch.tensor([float(iters_per_step)], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(w_, op=dist.ReduceOp.SUM)
+        iters_all = float(w_.item())
+    else:
+        elapsed_max, iters_all = elapsed, float(iters_per_step)
+
+    if rank == 0:
+        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+        cus, mhz = device_info["compute_units"], device_info["clock_mhz"]
+        peak_lane_ops = cus * 4 * 16 * mhz * 1e6              # fp64 VALU lane-ops/s (16 lanes/clk/SIMD)
+        peak_tflops = peak_lane_ops * 2 / 1e12                 # FMA = 2 flop -> 78.6 on MI355X
+        achieved_tflops = FLOPS_PER_PIXEL_ITER * iters_per_step / avg_kernel_s / 1e12
+        out_bytes = npix * 4
+        rec = {
+            "metric": "G pixel-iterations/s on 4096^2 tile, max_iter=1000 fp64",
+            "value": iters_all * args.steps / elapsed_max / 1e9,
+            "unit": "G pixel-iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (coordinates generated in-kernel from the view origin and stride; no RNG)",
+            "config": {"workload": f"{args.workload}: {desc}; one tile per GPU per step, int32 counts "
+                                   "written to resident HBM", "kernel": args.kernel,
+                       "pixels_per_step_per_gpu": npix, "pixel_iterations_per_step_per_gpu": iters_per_step,
+                       "never_escaped_pixels": never, "parallelism": f"{world} independent tile queue(s), no collective",
+                       "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus,
+                       "clock_mhz": mhz},
+            "roofline": {
+                "bound": "fp64_valu",
+                "achieved": achieved_tflops,
+                "peak": peak_tflops,
+                "unit": "TFLOP/s",
+                "frac": achieved_tflops / peak_tflops,
+                "traffic": None,
+                "kernel_ms_avg": avg_kernel_s * 1e3,
+                "kernel_ms_min": min(kernel_ms),
+                "flops_per_pixel_iteration": FLOPS_PER_PIXEL_ITER,
+                "parity_ceiling_frac": FLOPS_PER_PIXEL_ITER / (2.0 * VALU_OPS_PER_PIXEL_ITER),
+                "valu_slot_util": VALU_OPS_PER_PIXEL_ITER * iters_per_step / avg_kernel_s / peak_lane_ops,
+                "algorithmic_hbm_bytes_per_launch": out_bytes,
+                "hbm_GBps": out_bytes / avg_kernel_s / 1e9,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline and not fake:
+            rec["cpu_baseline"] = cpu_baseline(workload)
+        elif world == 1 and fake:
+            rec["cpu_baseline"] = None
+        print(json.dumps(rec), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+    if dev is not None:
+        dev.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""ctypes binding of libmbk_hip.so (C ABI: include/mbk.h).
+
+The library is built in-tree by ``distributedmandelbrot_amd.build`` and loaded from this directory.
+If it is missing the import of the product path FAILS LOUDLY -- there is no CPU fallback
+(the CPU oracle under oracle/ is test infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libmbk_hip.so")
+
+MBK_OK, MBK_ERR_INVALID, MBK_ERR_NO_DEVICE, MBK_ERR_HIP, MBK_ERR_NOMEM = range(5)
+MBK_WANT_COUNTS = 0x1
+MBK_WANT_BYTES = 0x2
+MBK_KERNEL_DEFAULT = 0x000
+MBK_KERNEL_SIMPLE = 0x100
+MBK_KERNEL_ASM = 0x200
+MBK_KERNEL_REFILL = 0x300
+KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MBK_KERNEL_ASM,
+           "refill": MBK_KERNEL_REFILL}
+MBK_CHUNK_DEFINITION = 4096
+MBK_CHUNK_BYTES = 4096 * 4096
+MBK_ABI_VERSION = 1
+
+
+class mbk_view(C.Structure):
+    _fields_ = [("start_r", C.c_double), ("start_i", C.c_double),
+                ("range_r", C.c_double), ("range_i", C.c_double),
+                ("width", C.c_uint32), ("height", C.c_uint32),
+                ("col0", C.c_uint32), ("row0", C.c_uint32),
+                ("ncols", C.c_uint32), ("nrows", C.c_uint32)]
+
+
+class mbk_stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_float), ("d2h_ms", C.c_float),
+                ("pixel_iterations", C.c_uint64), ("never_pixels", C.c_uint64),
+                ("all_bytes_zero", C.c_uint32), ("all_bytes_one", C.c_uint32)]
+
+
+class mbk_device_info(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64),
+                ("compute_units", C.c_int), ("clock_mhz", C.c_int),
+                ("wavefront_size", C.c_int), ("total_mem", C.c_uint64)]
+
+
+# symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against mbk.h
+SIGNATURES = {
+    "mbk_abi_version": (C.c_int, []),
+    "mbk_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mbk_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mbk_destroy": (None, [C.c_void_p]),
+    "mbk_last_error": (C.c_char_p, [C.c_void_p]),
+    "mbk_get_device_info": (C.c_int, [C.c_void_p, C.POINTER(mbk_device_info)]),
+    "mbk_host_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mbk_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mbk_datachunk_geometry": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double)]),
+    "mbk_view_launch": (C.c_int, [C.c_void_p, C.POINTER(mbk_view), C.c_uint32, C.c_uint32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mbk_view_compute": (C.c_int, [C.c_void_p, C.POINTER(mbk_view), C.c_uint32, C.c_uint32,
+                                   C.c_void_p, C.c_void_p, C.POINTER(mbk_stats)]),
+    "mbk_datachunk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                C.c_void_p, C.c_void_p, C.POINTER(mbk_stats)]),
+    "mbk_reduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                    C.POINTER(mbk_stats)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmbk_hip.so and declare every entry point.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: build it with `python -m distributedmandelbrot_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.mbk_abi_version() != MBK_ABI_VERSION:
+        raise ImportError("libmbk_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib

@@ -1,0 +1,420 @@
+// mbk_api.hip -- host side of libmbk_hip.so: the C ABI declared in include/mbk.h.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
+// -ffp-contract=off covers the HOST arithmetic in this file too (axis preparation, tile geometry):
+// every fp64 operation below must round individually, as CPython / numpy do for the reference
+// (DistributedMandelbrotWorkerCUDA.py:24-32,75-78).
+#include "../../include/mbk.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "mbk_kernels.h"
+
+using mbk::Axis;
+using mbk::ReduceOut;
+using mbk::TileArgs;
+
+struct mbk_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
+    int32_t *d_counts = nullptr;
+    uint8_t *d_bytes = nullptr;
+    size_t cap_px = 0;
+    ReduceOut *d_red = nullptr;
+    ReduceOut *h_red = nullptr;  // pinned
+    hipDeviceProp_t prop;
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int fail(mbk_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define MBK_HIP(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            return fail((ctx), MBK_ERR_HIP,                                                 \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                 \
+        }                                                                                   \
+    } while (0)
+
+// ---- host arithmetic (individually rounded; `volatile` keeps the compiler honest at any -O) ----
+
+static Axis make_axis(double start, double range, uint32_t n)
+{
+    Axis a;
+    std::memset(&a, 0, sizeof(a));
+    a.start = start;
+    a.n = n;
+    volatile double stop = start + range;
+    if (n <= 1) {
+        a.last = start;
+        a.div = 1.0;
+        return a;
+    }
+    volatile double delta = stop - start;
+    volatile double div = (double)(n - 1);
+    volatile double step = delta / div;
+    a.last = stop;
+    a.delta = delta;
+    a.div = div;
+    a.step = step;
+    a.step_is_zero = (step == 0.0) ? 1u : 0u;
+    return a;
+}
+
+static double axis_value_host(const Axis &a, uint32_t k)
+{
+    if (k + 1u == a.n) return a.last;
+    volatile double y;
+    if (a.step_is_zero) {
+        volatile double q = (double)k / a.div;
+        y = q * a.delta;
+    } else {
+        y = (double)k * a.step;
+    }
+    volatile double v = y + a.start;
+    return v;
+}
+
+// Coordinates must stay far from overflow so that no inf-inf = NaN can appear before the bailout
+// test fires (the hand-scheduled kernels compare the high word of |z|^2 as an integer).
+static const double kMaxCoord = 0x1p500;
+// fma(2, zr*zi, ci) == fl(fl((2*zr)*zi) + ci) unless zr*zi is subnormal AND ci is so small that
+// the last bit of a subnormal survives the addition.  |ci| >= 2^-900 (or ci == 0, where zi stays
+// exactly 0) rules that out; otherwise use the literal (2*zr)*zi instantiation.
+static const double kSafeImagMin = 0x1p-900;
+
+static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling)
+{
+    if (!v) return fail(ctx, MBK_ERR_INVALID, "view is NULL");
+    if (v->width == 0 || v->height == 0) return fail(ctx, MBK_ERR_INVALID, "empty view");
+    if (v->ncols == 0 || v->nrows == 0) return fail(ctx, MBK_ERR_INVALID, "empty window");
+    if ((uint64_t)v->col0 + v->ncols > v->width || (uint64_t)v->row0 + v->nrows > v->height)
+        return fail(ctx, MBK_ERR_INVALID, "window exceeds the view");
+    if ((uint64_t)v->ncols * v->nrows > (1ull << 31))
+        return fail(ctx, MBK_ERR_INVALID, "window larger than 2^31 pixels");
+    const double vals[6] = {v->start_r, v->start_i, v->range_r, v->range_i,
+                            v->start_r + v->range_r, v->start_i + v->range_i};
+    for (double x : vals)
+        if (!std::isfinite(x) || std::fabs(x) > kMaxCoord)
+            return fail(ctx, MBK_ERR_INVALID, "view coordinates must be finite and |x| <= 2^500");
+    bool safe = false;
+    const Axis im = make_axis(v->start_i, v->range_i, v->height);
+    for (uint32_t r = 0; r < v->nrows && !safe; ++r) {
+        const double ci = std::fabs(axis_value_host(im, v->row0 + r));
+        if (ci != 0.0 && ci < kSafeImagMin) safe = true;
+    }
+    *safe_doubling = safe;
+    return MBK_OK;
+}
+
+static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t flags,
+                       int32_t *d_counts, uint8_t *d_bytes, hipStream_t stream)
+{
+    bool safe = false;
+    int rc = validate_view(ctx, v, &safe);
+    if (rc != MBK_OK) return rc;
+    if (mrd > 0x7fffffffu) return fail(ctx, MBK_ERR_INVALID, "mrd must fit int32 (calc_mb_value returns int32)");
+    const bool wc = (flags & MBK_WANT_COUNTS) != 0, wb = (flags & MBK_WANT_BYTES) != 0;
+    if (!wc && !wb) return fail(ctx, MBK_ERR_INVALID, "flags select no output");
+    if (wc && !d_counts) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_COUNTS with NULL counts pointer");
+    if (wb && !d_bytes) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_BYTES with NULL bytes pointer");
+    if (wb && mrd == 0) return fail(ctx, MBK_ERR_INVALID, "mrd == 0 has no quantised form (division by zero)");
+
+    TileArgs a;
+    a.re = make_axis(v->start_r, v->range_r, v->width);
+    a.im = make_axis(v->start_i, v->range_i, v->height);
+    a.col0 = v->col0;
+    a.row0 = v->row0;
+    a.ncols = v->ncols;
+    a.nrows = v->nrows;
+    a.mrd = (int32_t)mrd;
+    a.quant_wide = (mrd >= (1u << 23)) ? 1u : 0u;
+    a.counts = wc ? d_counts : nullptr;
+    a.bytes = wb ? d_bytes : nullptr;
+
+    const uint32_t kernel = flags & MBK_KERNEL_MASK;
+    switch (kernel) {
+        case MBK_KERNEL_DEFAULT:
+        case MBK_KERNEL_SIMPLE: {
+            a.blocks_x = (v->ncols + 31u) / 32u;
+            const uint32_t by = (v->nrows + 7u) / 8u;
+            const dim3 grid(a.blocks_x * by), block(256);
+            if (safe || kernel == MBK_KERNEL_SIMPLE)
+                hipLaunchKernelGGL(mbk::tile_simple_kernel<false>, grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL(mbk::tile_simple_kernel<true>, grid, block, 0, stream, a);
+            break;
+        }
+        default:
+            return fail(ctx, MBK_ERR_INVALID, "unknown MBK_KERNEL_* selector");
+    }
+    MBK_HIP(ctx, hipGetLastError());
+    return MBK_OK;
+}
+
+static int ensure_buffers(mbk_ctx *ctx, size_t px)
+{
+    if (px <= ctx->cap_px) return MBK_OK;
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
+    ctx->d_counts = nullptr;
+    ctx->d_bytes = nullptr;
+    ctx->cap_px = 0;
+    MBK_HIP(ctx, hipMalloc((void **)&ctx->d_counts, px * sizeof(int32_t)));
+    MBK_HIP(ctx, hipMalloc((void **)&ctx->d_bytes, px));
+    ctx->cap_px = px;
+    return MBK_OK;
+}
+
+static int launch_reduce(mbk_ctx *ctx, const int32_t *d_counts, const uint8_t *d_bytes, uint64_t n,
+                         uint32_t mrd, hipStream_t stream)
+{
+    MBK_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(ReduceOut), stream));
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(mbk::reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
+                       d_bytes, n, mrd, ctx->d_red);
+    MBK_HIP(ctx, hipGetLastError());
+    MBK_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(ReduceOut), hipMemcpyDeviceToHost,
+                                stream));
+    return MBK_OK;
+}
+
+static void fill_stats_from_reduce(const mbk_ctx *ctx, mbk_stats *s, bool have_bytes)
+{
+    s->pixel_iterations = ctx->h_red->pixel_iterations;
+    s->never_pixels = ctx->h_red->never_pixels;
+    s->all_bytes_zero = have_bytes && ctx->h_red->any_byte_not_zero == 0 ? 1u : 0u;
+    s->all_bytes_one = have_bytes && ctx->h_red->any_byte_not_one == 0 ? 1u : 0u;
+}
+
+// ------------------------------------- C ABI ---------------------------------------------------
+
+extern "C" {
+
+int mbk_abi_version(void) { return MBK_ABI_VERSION; }
+
+int mbk_device_count(int *count)
+{
+    if (!count) return fail(nullptr, MBK_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, MBK_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return MBK_OK;
+}
+
+int mbk_create(int device, mbk_ctx **out)
+{
+    if (!out) return fail(nullptr, MBK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, MBK_ERR_NO_DEVICE,
+                    std::string("no HIP device visible (") + hipGetErrorString(e) +
+                        "); libmbk_hip has no CPU fallback");
+    if (device < 0 || device >= n) return fail(nullptr, MBK_ERR_NO_DEVICE, "device index out of range");
+    mbk_ctx *ctx = new (std::nothrow) mbk_ctx();
+    if (!ctx) return fail(nullptr, MBK_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+#define MBK_CREATE_HIP(call)                                                        \
+    do {                                                                            \
+        hipError_t e2_ = (call);                                                    \
+        if (e2_ != hipSuccess) {                                                    \
+            fail(nullptr, MBK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e2_)); \
+            mbk_destroy(ctx);                                                       \
+            return MBK_ERR_HIP;                                                     \
+        }                                                                           \
+    } while (0)
+    MBK_CREATE_HIP(hipSetDevice(device));
+    MBK_CREATE_HIP(hipGetDeviceProperties(&ctx->prop, device));
+    if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, MBK_ERR_NO_DEVICE,
+             std::string("device is ") + ctx->prop.gcnArchName + ", this library is built for gfx950 only");
+        mbk_destroy(ctx);
+        return MBK_ERR_NO_DEVICE;
+    }
+    MBK_CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_k0));
+    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_k1));
+    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_c0));
+    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_c1));
+    MBK_CREATE_HIP(hipMalloc((void **)&ctx->d_red, sizeof(ReduceOut)));
+    MBK_CREATE_HIP(hipHostMalloc((void **)&ctx->h_red, sizeof(ReduceOut), hipHostMallocDefault));
+#undef MBK_CREATE_HIP
+    *out = ctx;
+    return MBK_OK;
+}
+
+void mbk_destroy(mbk_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
+    if (ctx->d_red) (void)hipFree(ctx->d_red);
+    if (ctx->h_red) (void)hipHostFree(ctx->h_red);
+    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
+    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
+    if (ctx->ev_c0) (void)hipEventDestroy(ctx->ev_c0);
+    if (ctx->ev_c1) (void)hipEventDestroy(ctx->ev_c1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *mbk_last_error(const mbk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int mbk_get_device_info(mbk_ctx *ctx, mbk_device_info *info)
+{
+    if (!ctx || !info) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    std::memset(info, 0, sizeof(*info));
+    std::snprintf(info->name, sizeof(info->name), "%s", ctx->prop.name);
+    std::snprintf(info->arch, sizeof(info->arch), "%s", ctx->prop.gcnArchName);
+    info->compute_units = ctx->prop.multiProcessorCount;
+    info->clock_mhz = ctx->prop.clockRate / 1000;
+    info->wavefront_size = ctx->prop.warpSize;
+    info->total_mem = ctx->prop.totalGlobalMem;
+    return MBK_OK;
+}
+
+int mbk_host_alloc(mbk_ctx *ctx, uint64_t bytes, void **out)
+{
+    if (!ctx || !out || bytes == 0) return fail(ctx, MBK_ERR_INVALID, "bad argument");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    MBK_HIP(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return MBK_OK;
+}
+
+int mbk_host_free(mbk_ctx *ctx, void *ptr)
+{
+    if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
+    if (!ptr) return MBK_OK;
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    MBK_HIP(ctx, hipHostFree(ptr));
+    return MBK_OK;
+}
+
+int mbk_datachunk_geometry(uint32_t level, uint32_t index_real, uint32_t index_imag,
+                           double *start_r, double *start_i, double *range)
+{
+    if (!start_r || !start_i || !range) return fail(nullptr, MBK_ERR_INVALID, "NULL output pointer");
+    if (level == 0) return fail(nullptr, MBK_ERR_INVALID, "level must be > 0 (DataChunk.cs:99-100)");
+    if (index_real >= level || index_imag >= level)
+        return fail(nullptr, MBK_ERR_INVALID, "chunk index must be < level (DataChunk.cs:102-106)");
+    // WorkerCUDA.py:75-78: chunk_range = (MAX_AXIS - MIN_AXIS) / level; start = MIN_AXIS + chunk_range*index
+    volatile double chunk_range = (2.0 - (-2.0)) / (double)level;
+    volatile double pr = chunk_range * (double)index_real;
+    volatile double pi = chunk_range * (double)index_imag;
+    *range = chunk_range;
+    *start_r = -2.0 + pr;
+    *start_i = -2.0 + pi;
+    return MBK_OK;
+}
+
+int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                    int32_t *d_counts, uint8_t *d_bytes, void *hip_stream)
+{
+    if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    return launch_tile(ctx, view, mrd, flags, d_counts, d_bytes, s);
+}
+
+int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                     int32_t *h_counts, uint8_t *h_bytes, mbk_stats *stats)
+{
+    if (!ctx || !view) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    const bool wc = (flags & MBK_WANT_COUNTS) != 0, wb = (flags & MBK_WANT_BYTES) != 0;
+    if (wc && !h_counts) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_COUNTS with NULL counts pointer");
+    if (wb && !h_bytes) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_BYTES with NULL bytes pointer");
+    bool dummy;
+    int rc = validate_view(ctx, view, &dummy);
+    if (rc != MBK_OK) return rc;
+    const size_t px = (size_t)view->ncols * view->nrows;
+    rc = ensure_buffers(ctx, px);
+    if (rc != MBK_OK) return rc;
+    // counts are always produced on the device (they feed the stats reduction); only what the
+    // caller asked for crosses PCIe.
+    const uint32_t dev_flags = (flags & MBK_KERNEL_MASK) | MBK_WANT_COUNTS | (wb ? MBK_WANT_BYTES : 0u);
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    rc = launch_tile(ctx, view, mrd, dev_flags, ctx->d_counts, ctx->d_bytes, ctx->stream);
+    if (rc != MBK_OK) return rc;
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    rc = launch_reduce(ctx, ctx->d_counts, wb ? ctx->d_bytes : nullptr, px, mrd, ctx->stream);
+    if (rc != MBK_OK) return rc;
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
+    if (wb) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, ctx->d_bytes, px, hipMemcpyDeviceToHost, ctx->stream));
+    if (wc)
+        MBK_HIP(ctx, hipMemcpyAsync(h_counts, ctx->d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_c1, ctx->stream));
+    MBK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev_k0, ctx->ev_k1));
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->d2h_ms, ctx->ev_c0, ctx->ev_c1));
+        fill_stats_from_reduce(ctx, stats, wb);
+    }
+    return MBK_OK;
+}
+
+int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_real,
+                  uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, mbk_stats *stats)
+{
+    if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
+    if (!h_bytes) return fail(ctx, MBK_ERR_INVALID, "h_bytes is NULL");
+    mbk_view v;
+    double sr, si, range;
+    int rc = mbk_datachunk_geometry(level, index_real, index_imag, &sr, &si, &range);
+    if (rc != MBK_OK) {
+        ctx->err = g_err;
+        return rc;
+    }
+    v.start_r = sr;
+    v.start_i = si;
+    v.range_r = range;
+    v.range_i = range;
+    v.width = v.height = MBK_CHUNK_DEFINITION;
+    v.col0 = v.row0 = 0;
+    v.ncols = v.nrows = MBK_CHUNK_DEFINITION;
+    const uint32_t flags = MBK_WANT_BYTES | (h_counts ? MBK_WANT_COUNTS : 0u);
+    return mbk_view_compute(ctx, &v, mrd, flags, h_counts, h_bytes, stats);
+}
+
+int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_t mrd,
+                      void *hip_stream, mbk_stats *stats)
+{
+    if (!ctx || !d_counts || !stats) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    int rc = launch_reduce(ctx, d_counts, nullptr, n, mrd, s);
+    if (rc != MBK_OK) return rc;
+    MBK_HIP(ctx, hipStreamSynchronize(s));
+    std::memset(stats, 0, sizeof(*stats));
+    fill_stats_from_reduce(ctx, stats, false);
+    return MBK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// mbk_kernels.h -- device code of libmbk_hip.so: escape-time kernels for gfx950 (MI355X / CDNA4).
+//
+// What is computed (reference = DistributedMandelbrotWorkerCUDA.py, "W.py"):
+//   coordinates   x[k] = fl(fl(k*step) + start), x[n-1] = stop          np.linspace, W.py:24-32
+//   escape loop   z = c; for n in 1..mrd-1: z = z*z + c; if |z|^2 >= 4 return n; return 0   W.py:39-68
+//   quantiser     byte = ceil(count*256/mrd) mod 256                     W.py:96-98
+//
+// Bit-exactness rules for everything in this file:
+//   * the translation unit is compiled with -ffp-contract=off (hipcc contracts by default);
+//   * the only fused operation ever used is fma(2.0, zr*zi, ci): 2*p is exact, so it rounds once,
+//     exactly like fl(fl((2*zr)*zi) + ci) -- EXCEPT when zr*zi is subnormal.  The host therefore
+//     selects the "exact doubling" instantiation (kFmaDouble = false) whenever a non-zero imaginary
+//     coordinate is small enough for that to matter (see mbk_api.hip: needs_safe_doubling);
+//   * squares are shared between the bailout test of step n and the update of step n+1 (same
+//     operands, same operation, same rounding).
+//
+// Roofline that bounds these kernels: fp64 VALU issue rate (not HBM, not MFMA): 7 fp64 VALU
+// operations per pixel-iteration (3 mul, 3 add, 1 fma) + one 32-bit compare; algorithmic HBM traffic
+// is the 4 B (int32) and/or 1 B (uint8) written per pixel, nothing is read.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mbk {
+
+// One axis of a view, prepared on the host with individually rounded fp64 operations.
+struct Axis {
+    double start;  // x[0]
+    double step;   // fl(delta / (n-1))
+    double last;   // value of sample n-1: stop (n > 1) or start (n == 1)
+    double delta;  // fl(stop - start)           (only used by numpy's step == 0 fallback)
+    double div;    // (double)(n-1)              (idem)
+    uint32_t n;
+    uint32_t step_is_zero;  // numpy: y = (k/div)*delta instead of k*step
+};
+
+struct TileArgs {
+    Axis re, im;
+    uint32_t col0, row0, ncols, nrows;
+    uint32_t blocks_x;    // workgroups per row of 8-pixel-high block rows (1-D grid)
+    int32_t mrd;
+    uint32_t quant_wide;  // 1: count*256+mrd-1 does not fit 32 bits -> 64-bit quantiser division
+    int32_t *counts;      // may be null
+    uint8_t *bytes;       // may be null
+};
+
+// np.linspace sample k (numpy/_core/function_base.py): two roundings, endpoint pinned.
+__device__ __forceinline__ double axis_value(const Axis &a, uint32_t k)
+{
+    double y;
+    if (a.step_is_zero) {
+        double q = (double)k / a.div;
+        y = q * a.delta;
+    } else {
+        y = (double)k * a.step;
+    }
+    double v = y + a.start;
+    return (k + 1u == a.n) ? a.last : v;
+}
+
+// W.py:96-98 in exact integer form: ceil(count*256/mrd) mod 256 (proved equal to the float form:
+// tests/test_oracle.py::test_quantiser_integer_form).
+__device__ __forceinline__ uint8_t quantise(int32_t count, int32_t mrd, uint32_t wide)
+{
+    if (wide) {
+        uint64_t x = (uint64_t)(uint32_t)count * 256ull + (uint64_t)(uint32_t)mrd - 1ull;
+        return (uint8_t)(x / (uint64_t)(uint32_t)mrd);
+    }
+    uint32_t x = (uint32_t)count * 256u + (uint32_t)mrd - 1u;
+    return (uint8_t)(x / (uint32_t)mrd);
+}
+
+// The reference loop for one pixel.  kFmaDouble selects how fl(2*zr*zi + ci) is formed.
+template <bool kFmaDouble>
+__device__ __forceinline__ int32_t escape_count(double cr, double ci, int32_t mrd)
+{
+    double zr = cr, zi = ci;
+    double a = zr * zr, b = zi * zi;
+    int32_t result = 0;
+    for (int32_t n = 1; n < mrd; ++n) {
+        double t = a - b;
+        double zi_new;
+        if (kFmaDouble) {
+            double p = zr * zi;
+            zi_new = __builtin_fma(2.0, p, ci);
+        } else {
+            double w = 2.0 * zr;
+            double u = w * zi;
+            zi_new = u + ci;
+        }
+        zr = t + cr;
+        zi = zi_new;
+        a = zr * zr;
+        b = zi * zi;
+        double m = a + b;
+        if (m >= 4.0) {
+            result = n;
+            break;
+        }
+    }
+    return result;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel "simple": one lane per pixel, one 8x8 pixel block per wavefront (compact blocks keep the
+// 64 lanes' iteration counts coherent: SURVEY.md P4 lane efficiency 0.90 vs 0.77 for 64x1 strips),
+// four wavefronts side by side per 256-thread workgroup (32 x 8 pixels).  The divergent loop exits a
+// wavefront as soon as all 64 lanes have escaped (EXEC == 0).
+// ---------------------------------------------------------------------------------------------
+template <bool kFmaDouble>
+__global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t by = blockIdx.x / p.blocks_x, bx = blockIdx.x - by * p.blocks_x;
+    const uint32_t lc = bx * 32u + wave * 8u + (lane & 7u);  // column inside the window
+    const uint32_t lr = by * 8u + (lane >> 3);               // row inside the window
+    if (lc >= p.ncols || lr >= p.nrows) return;
+    const double cr = axis_value(p.re, p.col0 + lc);
+    const double ci = axis_value(p.im, p.row0 + lr);
+    const int32_t count = escape_count<kFmaDouble>(cr, ci, p.mrd);
+    const size_t o = (size_t)lr * p.ncols + lc;
+    if (p.counts) p.counts[o] = count;
+    if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reduction over finished results: pixel-iterations, never-escaped pixels, all-zero / all-one byte
+// flags (DataChunk.cs:82,87).  HBM-bound, 4-5 B/pixel read once; not part of the timed hot loop.
+// ---------------------------------------------------------------------------------------------
+struct ReduceOut {
+    unsigned long long pixel_iterations;
+    unsigned long long never_pixels;
+    unsigned int any_byte_not_zero;
+    unsigned int any_byte_not_one;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void reduce_kernel(const int32_t *__restrict__ counts,
+                                                     const uint8_t *__restrict__ bytes,
+                                                     uint64_t n, uint32_t mrd, ReduceOut *out)
+{
+    const unsigned long long cap = mrd > 1u ? (unsigned long long)mrd - 1ull : 0ull;
+    unsigned long long iters = 0, never = 0;
+    unsigned int nz = 0, no = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (counts) {
+            int32_t c = counts[i];
+            iters += c > 0 ? (unsigned long long)c : cap;
+            never += c == 0 ? 1ull : 0ull;
+        }
+        if (bytes) {
+            uint8_t b = bytes[i];
+            nz |= (b != 0);
+            no |= (b != 1);
+        }
+    }
+    iters = wave_sum_u64(iters);
+    never = wave_sum_u64(never);
+    const unsigned long long nzb = __ballot(nz != 0), nob = __ballot(no != 0);
+    if ((threadIdx.x & 63u) == 0) {
+        if (iters) atomicAdd(&out->pixel_iterations, iters);
+        if (never) atomicAdd(&out->never_pixels, never);
+        if (nzb) atomicOr(&out->any_byte_not_zero, 1u);
+        if (nob) atomicOr(&out->any_byte_not_one, 1u);
+    }
+}
+
+}  // namespace mbk

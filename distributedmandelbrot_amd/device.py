@@ -1,0 +1,186 @@
+"""MandelbrotDevice -- one GPU context over the C ABI (include/mbk.h).
+
+Mirrors, for a generic view, what the reference's ``process_workload`` does for a DataChunk tile
+(DistributedMandelbrotWorkerCUDA.py:70-100, "WorkerCUDA.py"): coordinates (gen_arrays, :19-37),
+the escape-time kernel (calc_mb_value, :39-68) and the uint8 quantiser (:96-98) -- all on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+class MbkError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libmbk_hip status {status}: {message}")
+        self.status = status
+
+
+@dataclass(frozen=True)
+class View:
+    """width x height samples of [start_r, start_r+range_r] x [start_i, start_i+range_i], endpoints
+    included (np.linspace semantics, WorkerCUDA.py:24-32)."""
+    start_r: float
+    start_i: float
+    range_r: float
+    range_i: float
+    width: int
+    height: int
+
+    @staticmethod
+    def centered(center_r: float, center_i: float, span: float, width: int, height: Optional[int] = None):
+        height = width if height is None else height
+        return View(center_r - span / 2, center_i - span / 2, span, span, width, height)
+
+
+@dataclass
+class TileStats:
+    kernel_ms: float
+    d2h_ms: float
+    pixel_iterations: int
+    never_pixels: int
+    all_bytes_zero: bool   # DataChunk.IsNeverChunk (DataChunk.cs:82)
+    all_bytes_one: bool    # DataChunk.IsImmediateChunk (DataChunk.cs:87)
+
+
+def device_count() -> int:
+    lib = L.load()
+    n = C.c_int(0)
+    st = lib.mbk_device_count(C.byref(n))
+    if st != L.MBK_OK:
+        return 0
+    return n.value
+
+
+def datachunk_geometry(level: int, index_real: int, index_imag: int) -> Tuple[float, float, float]:
+    """(start_r, start_i, range) of a DataChunk tile: WorkerCUDA.py:75-78 == DataChunk.cs:32-33,59-66."""
+    lib = L.load()
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    st = lib.mbk_datachunk_geometry(level, index_real, index_imag, C.byref(a), C.byref(b), C.byref(c))
+    if st != L.MBK_OK:
+        raise MbkError(st, (lib.mbk_last_error(None) or b"").decode())
+    return a.value, b.value, c.value
+
+
+class MandelbrotDevice:
+    """One mbk_ctx == one GPU.  Not thread-safe: use one host thread per instance."""
+
+    def __init__(self, device: int = 0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        st = self._lib.mbk_create(device, C.byref(h))
+        if st != L.MBK_OK:
+            raise MbkError(st, (self._lib.mbk_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+        self._pinned = []
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            for p in self._pinned:
+                self._lib.mbk_host_free(self._h, p)
+            self._pinned = []
+            self._lib.mbk_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int) -> None:
+        if st != L.MBK_OK:
+            raise MbkError(st, (self._lib.mbk_last_error(self._h) or b"").decode())
+
+    # -- queries ---------------------------------------------------------------------------
+    def info(self) -> dict:
+        inf = L.mbk_device_info()
+        self._check(self._lib.mbk_get_device_info(self._h, C.byref(inf)))
+        return {"name": inf.name.decode(), "arch": inf.arch.decode(),
+                "compute_units": inf.compute_units, "clock_mhz": inf.clock_mhz,
+                "wavefront_size": inf.wavefront_size, "total_mem": inf.total_mem}
+
+    def pinned_empty(self, shape, dtype) -> np.ndarray:
+        """A numpy array over pinned host memory (freed when the device is closed)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.mbk_host_alloc(self._h, max(n, 1), C.byref(p)))
+        self._pinned.append(p)
+        buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    # -- compute ---------------------------------------------------------------------------
+    @staticmethod
+    def _cview(view: View, window) -> L.mbk_view:
+        col0, row0, ncols, nrows = window if window is not None else (0, 0, view.width, view.height)
+        return L.mbk_view(view.start_r, view.start_i, view.range_r, view.range_i,
+                          view.width, view.height, col0, row0, ncols, nrows)
+
+    def compute_view(self, view: View, mrd: int, *, window=None, want_counts: bool = True,
+                     want_bytes: bool = True, kernel: str = "default",
+                     out_counts: Optional[np.ndarray] = None, out_bytes: Optional[np.ndarray] = None):
+        """Synchronous: returns (counts int32[nrows,ncols] | None, bytes uint8[nrows,ncols] | None, TileStats)."""
+        cv = self._cview(view, window)
+        shape = (cv.nrows, cv.ncols)
+        flags = L.KERNELS[kernel]
+        counts = byts = None
+        if want_counts:
+            counts = out_counts if out_counts is not None else np.empty(shape, np.int32)
+            assert counts.dtype == np.int32 and counts.size == shape[0] * shape[1] and counts.flags.c_contiguous
+            flags |= L.MBK_WANT_COUNTS
+        if want_bytes:
+            byts = out_bytes if out_bytes is not None else np.empty(shape, np.uint8)
+            assert byts.dtype == np.uint8 and byts.size == shape[0] * shape[1] and byts.flags.c_contiguous
+            flags |= L.MBK_WANT_BYTES
+        st = L.mbk_stats()
+        self._check(self._lib.mbk_view_compute(
+            self._h, C.byref(cv), mrd, flags,
+            counts.ctypes.data if counts is not None else None,
+            byts.ctypes.data if byts is not None else None, C.byref(st)))
+        return counts, byts, _stats(st)
+
+    def datachunk(self, level: int, mrd: int, index_real: int, index_imag: int, *,
+                  want_counts: bool = False, out_bytes: Optional[np.ndarray] = None):
+        """The reference's process_workload (WorkerCUDA.py:70-100): uint8[16777216] for one tile.
+        Returns (bytes uint8[16777216], counts int32[16777216] | None, TileStats)."""
+        byts = out_bytes if out_bytes is not None else np.empty(L.MBK_CHUNK_BYTES, np.uint8)
+        assert byts.dtype == np.uint8 and byts.size == L.MBK_CHUNK_BYTES and byts.flags.c_contiguous
+        counts = np.empty(L.MBK_CHUNK_BYTES, np.int32) if want_counts else None
+        st = L.mbk_stats()
+        self._check(self._lib.mbk_datachunk(
+            self._h, level, mrd, index_real, index_imag, byts.ctypes.data,
+            counts.ctypes.data if counts is not None else None, C.byref(st)))
+        return byts, counts, _stats(st)
+
+    def launch_view(self, view: View, mrd: int, *, d_counts: int = 0, d_bytes: int = 0,
+                    stream: int = 0, window=None, kernel: str = "default") -> None:
+        """Asynchronous launch on raw DEVICE pointers (e.g. torch tensors' data_ptr()) on ``stream``
+        (a hipStream_t as int; 0 = the context's own stream)."""
+        cv = self._cview(view, window)
+        flags = L.KERNELS[kernel] | (L.MBK_WANT_COUNTS if d_counts else 0) | (L.MBK_WANT_BYTES if d_bytes else 0)
+        self._check(self._lib.mbk_view_launch(self._h, C.byref(cv), mrd, flags,
+                                              d_counts or None, d_bytes or None, stream or None))
+
+    def reduce_counts(self, d_counts: int, n: int, mrd: int, stream: int = 0) -> TileStats:
+        st = L.mbk_stats()
+        self._check(self._lib.mbk_reduce_counts(self._h, d_counts, n, mrd, stream or None, C.byref(st)))
+        return _stats(st)
+
+
+def _stats(st: L.mbk_stats) -> TileStats:
+    return TileStats(float(st.kernel_ms), float(st.d2h_ms), int(st.pixel_iterations),
+                     int(st.never_pixels), bool(st.all_bytes_zero), bool(st.all_bytes_one))

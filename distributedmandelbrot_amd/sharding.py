@@ -1,0 +1,102 @@
+"""Sharding one view over the GPUs of a node: row bands + a plain per-GPU work queue.
+
+The escape-time path has no exchange step (every pixel depends only on its own c), so there is no
+collective: the shard unit is a contiguous band of rows of the view (contiguous in the output, one
+D2H per band).  Cost per band varies by >100x (in-set vs far exterior), hence dynamic assignment
+from one shared cursor when the GPUs live in one process (`render_view`), and an interleaved static
+assignment when there is one process per GPU (`rank_bands`, used by bench.py under torchrun).
+
+The reference shards the same way one level up: the Distributer leases whole 4096x4096 tiles to
+whichever worker asks next (Distributer.cs:335-353).
+"""
+from __future__ import annotations
+
+import threading
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class Band:
+    index: int
+    row0: int
+    nrows: int
+
+
+def make_bands(height: int, band_rows: int) -> List[Band]:
+    if height <= 0 or band_rows <= 0:
+        raise ValueError("height and band_rows must be positive")
+    return [Band(i, r, min(band_rows, height - r)) for i, r in enumerate(range(0, height, band_rows))]
+
+
+def rank_bands(bands: Sequence[Band], rank: int, world_size: int) -> List[Band]:
+    """Static interleaved assignment for one-process-per-GPU runs: rank r takes bands r, r+W, ...
+    (neighbouring bands cost about the same, so interleaving balances without communication)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    return [b for b in bands if b.index % world_size == rank]
+
+
+class WorkQueue:
+    """The 'plain per-GPU work queue': one shared cursor, each GPU feeder pops the next item."""
+
+    def __init__(self, items: Sequence):
+        self._items = list(items)
+        self._next = 0
+        self._lock = threading.Lock()
+
+    def pop(self):
+        with self._lock:
+            if self._next >= len(self._items):
+                return None
+            item = self._items[self._next]
+            self._next += 1
+            return item
+
+    def __len__(self) -> int:
+        return len(self._items)
+
+
+def render_view(devices: Sequence, view, mrd: int, *, band_rows: int = 128, want_counts: bool = True,
+                want_bytes: bool = True, kernel: str = "default"
+                ) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], List[dict]]:
+    """Compute a whole view on several GPUs of this process: one host thread per device pulling row
+    bands from a shared WorkQueue.  `devices` are MandelbrotDevice-like objects (anything with
+    compute_view(view, mrd, window=..., want_counts=..., want_bytes=..., kernel=...)).
+    Returns (counts | None, bytes | None, per-device stats)."""
+    bands = make_bands(view.height, band_rows)
+    queue = WorkQueue(bands)
+    counts = np.empty((view.height, view.width), np.int32) if want_counts else None
+    byts = np.empty((view.height, view.width), np.uint8) if want_bytes else None
+    per_dev = [{"bands": 0, "pixel_iterations": 0, "kernel_ms": 0.0} for _ in devices]
+    errors: List[BaseException] = []
+
+    def feeder(slot: int) -> None:
+        dev = devices[slot]
+        try:
+            while True:
+                band = queue.pop()
+                if band is None:
+                    return
+                c, b, st = dev.compute_view(view, mrd, window=(0, band.row0, view.width, band.nrows),
+                                            want_counts=want_counts, want_bytes=want_bytes, kernel=kernel)
+                if counts is not None:
+                    counts[band.row0:band.row0 + band.nrows] = c
+                if byts is not None:
+                    byts[band.row0:band.row0 + band.nrows] = b
+                per_dev[slot]["bands"] += 1
+                per_dev[slot]["pixel_iterations"] += st.pixel_iterations
+                per_dev[slot]["kernel_ms"] += st.kernel_ms
+        except BaseException as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=feeder, args=(i,), daemon=True) for i in range(len(devices))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return counts, byts, per_dev

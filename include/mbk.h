@@ -1,0 +1,151 @@
+/*
+ * mbk.h -- C ABI of libmbk_hip.so, the MI355X (gfx950) Mandelbrot tile kernel library.
+ *
+ * The reference (ofsouzap/DistributedMandelbrot) has NO in-process plugin / FFI interface: its only
+ * compute path is a numba-CUDA ufunc inside a Python worker script.  The seam a drop-in must honour
+ * is the worker<->Distributer TCP protocol (spoken by distributedmandelbrot_amd/worker.py); the
+ * in-process seam is the worker's `process_workload(level, mrd, index_real, index_imag)`.  Each entry
+ * point below names the reference code it replaces.  Paths are relative to the reference root;
+ * "WorkerCUDA.py" = DistributedMandelbrotWorkerCUDA/DistributedMandelbrotWorkerCUDA.py.
+ *
+ * Conventions: plain C symbols; every call returns an int status (MBK_OK == 0); no exceptions, no
+ * C++ or torch types cross the boundary; output buffers are caller-owned; one mbk_ctx per GPU; a
+ * ctx is NOT thread-safe (use one host thread per ctx -- ctypes releases the GIL during calls).
+ * There is NO CPU fallback: without a usable gfx950 device mbk_create fails with MBK_ERR_NO_DEVICE.
+ *
+ * Arithmetic contract: IEEE-754 binary64, every operation individually
+ * rounded, no FMA contraction of the reference's expressions; iteration counts are bit-identical to
+ * a strict evaluation of WorkerCUDA.py:39-68 on coordinates bit-identical to np.linspace's.
+ */
+#ifndef MBK_H
+#define MBK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBK_ABI_VERSION 1
+
+/* DataChunk.cs:20 (dataChunkRange), WorkerCUDA.py:80 (definition = 4096). */
+#define MBK_CHUNK_DEFINITION 4096u
+/* DataChunk.cs:27 (dataChunkSize): bytes in one tile result on the wire (Distributer.cs:415-416). */
+#define MBK_CHUNK_BYTES (4096u * 4096u)
+
+enum mbk_status {
+    MBK_OK = 0,
+    MBK_ERR_INVALID = 1,   /* bad argument (NULL pointer, empty window outside the view, mrd > INT32_MAX ...) */
+    MBK_ERR_NO_DEVICE = 2, /* no HIP device / device index out of range / not a gfx950-class GPU */
+    MBK_ERR_HIP = 3,       /* a HIP runtime call failed; see mbk_last_error */
+    MBK_ERR_NOMEM = 4
+};
+
+/* flags for the compute calls */
+#define MBK_WANT_COUNTS 0x1u /* write int32 escape indices (what calc_mb_value returns, WorkerCUDA.py:39) */
+#define MBK_WANT_BYTES 0x2u  /* write the quantised uint8 (WorkerCUDA.py:96-98) -- fused on device */
+/* Kernel selection (bits 8..11).  0 = default (fastest parity-exact kernel). Others exist so that the
+ * parity tests and bench.py can A/B every shipped kernel variant; all of them are bit-exact. */
+#define MBK_KERNEL_SHIFT 8
+#define MBK_KERNEL_MASK 0xF00u
+#define MBK_KERNEL_DEFAULT 0x000u
+#define MBK_KERNEL_SIMPLE 0x100u /* one lane per pixel, compiler-scheduled loop, literal (2*zr)*zi form */
+#define MBK_KERNEL_ASM 0x200u    /* one lane per pixel, hand-scheduled gfx950 loop */
+#define MBK_KERNEL_REFILL 0x300u /* persistent waves with lane refill (deep-zoom divergence) */
+
+typedef struct mbk_ctx mbk_ctx;
+
+/*
+ * A view: width x height samples of [start_r, start_r+range_r] x [start_i, start_i+range_i], both
+ * endpoints included -- exactly gen_arrays' two np.linspace calls (WorkerCUDA.py:24-32) with
+ * `definition` generalised to width/height.  The window (col0,row0,ncols,nrows) selects which
+ * samples are computed (row bands are the multi-GPU shard unit); coordinates always come from the
+ * FULL view's linspace, so a banded view is bit-identical to the whole one.
+ * Output layout: element (row-row0)*ncols + (col-col0); real is the fast axis (np.tile, :34),
+ * imaginary the slow one (np.repeat, :35); row 0 is start_i.
+ */
+typedef struct mbk_view {
+    double start_r, start_i;
+    double range_r, range_i;
+    uint32_t width, height;
+    uint32_t col0, row0, ncols, nrows;
+} mbk_view;
+
+typedef struct mbk_stats {
+    float kernel_ms;           /* hipEvent time of the escape-time kernel launch(es) */
+    float d2h_ms;              /* hipEvent time of the device->host copies */
+    uint64_t pixel_iterations; /* sum over pixels of (count if count>0 else mrd-1), from the kernel's own counts */
+    uint64_t never_pixels;     /* pixels with count == 0 (never escaped) */
+    uint32_t all_bytes_zero;   /* 1 iff every quantised byte == 0: DataChunk.IsNeverChunk,     DataChunk.cs:82 */
+    uint32_t all_bytes_one;    /* 1 iff every quantised byte == 1: DataChunk.IsImmediateChunk, DataChunk.cs:87 */
+} mbk_stats;
+
+typedef struct mbk_device_info {
+    char name[128];
+    char arch[64];
+    int compute_units;
+    int clock_mhz;       /* max engine clock */
+    int wavefront_size;
+    uint64_t total_mem;
+} mbk_device_info;
+
+int mbk_abi_version(void);
+
+/* Number of HIP devices visible to this process. */
+int mbk_device_count(int *count);
+
+/* One context per GPU: device selection, a private stream, events, grow-on-demand device buffers.
+ * Replaces the implicit default-CUDA-device context numba creates at WorkerCUDA.py:87. */
+int mbk_create(int device, mbk_ctx **out);
+void mbk_destroy(mbk_ctx *ctx);
+
+/* Message for the last failing call on this ctx (ctx may be NULL for mbk_create failures).
+ * The string stays valid until the next call on the same ctx / thread. */
+const char *mbk_last_error(const mbk_ctx *ctx);
+
+int mbk_get_device_info(mbk_ctx *ctx, mbk_device_info *info);
+
+/* Pinned host memory for result buffers (direct DMA target of the D2H copy).  Optional: any host
+ * pointer is accepted by the compute calls. */
+int mbk_host_alloc(mbk_ctx *ctx, uint64_t bytes, void **out);
+int mbk_host_free(mbk_ctx *ctx, void *ptr);
+
+/* Tile geometry: WorkerCUDA.py:75-78 == DataChunk.cs:32-33,59-66.
+ * range = 4/level; start = -2 + range*index (each operation individually rounded).
+ * MBK_ERR_INVALID if level == 0 or an index >= level (DataChunk.cs:99-106). */
+int mbk_datachunk_geometry(uint32_t level, uint32_t index_real, uint32_t index_imag,
+                           double *start_r, double *start_i, double *range);
+
+/*
+ * Asynchronous launch on DEVICE pointers, on the caller's HIP stream (NULL = the ctx's own stream).
+ * Replaces gen_arrays (WorkerCUDA.py:19-37: coordinates are generated in-kernel), the two H2D copies
+ * (:87-88), the ufunc launch `calc_mb_value(r_device, i_device, mrd, out=out_device)` (:92) and,
+ * with MBK_WANT_BYTES, the host quantiser (:96-98).  d_counts: int32[nrows*ncols] (or NULL without
+ * MBK_WANT_COUNTS); d_bytes: uint8[nrows*ncols] (or NULL without MBK_WANT_BYTES).
+ * mrd is the reference's "maximum recursion depth": at most mrd-1 updates, result in {0} U [1, mrd-1].
+ */
+int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                    int32_t *d_counts, uint8_t *d_bytes, void *hip_stream);
+
+/* Synchronous: launch + D2H into HOST buffers (either may be NULL according to flags) + stats.
+ * Replaces WorkerCUDA.py:82-98 for a generic view. */
+int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                     int32_t *h_counts, uint8_t *h_bytes, mbk_stats *stats);
+
+/* Synchronous: one 4096x4096 DataChunk tile, exactly the reference's
+ * `process_workload(level, mrd, index_real, index_imag) -> uint8[16777216]` (WorkerCUDA.py:70-100).
+ * h_bytes: MBK_CHUNK_BYTES bytes, the payload the worker sends after 0x20 (WorkerCUDA.py:168).
+ * h_counts: optional int32[16777216] (NULL to skip its D2H). */
+int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_real,
+                  uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, mbk_stats *stats);
+
+/* Device-side reduction over int32 counts already in HBM (asynchronous part on hip_stream, then a
+ * stream sync): fills stats->pixel_iterations and stats->never_pixels.  Used by bench.py to turn
+ * kernel time into pixel-iterations/s from the kernel's own output. */
+int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_t mrd,
+                      void *hip_stream, mbk_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBK_H */

@@ -1,0 +1,167 @@
+/*
+ * mandel_oracle.c -- CPU ORACLE for the Mandelbrot tile escape-time path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (distributedmandelbrot_amd/)
+ * never imports, links or executes anything in oracle/.
+ *
+ * It restates, in strict IEEE-754 binary64 with every operation individually rounded
+ * (compile with -ffp-contract=off, never -ffast-math), the reference's only implementation
+ * of the hot path.  All citations are relative to /root/reference/ and
+ * "WorkerCUDA.py" = DistributedMandelbrotWorkerCUDA/DistributedMandelbrotWorkerCUDA.py:
+ *
+ *   mbo_geometry   <- process_workload, WorkerCUDA.py:75-78  (== DataChunk.cs:32-33,59-66)
+ *   mbo_axis       <- gen_arrays, WorkerCUDA.py:24-32 (np.linspace with endpoint; numpy is an
+ *                     un-vendored, un-pinned dependency -- its published algorithm,
+ *                     numpy/_core/function_base.py `linspace`, is restated here and was
+ *                     checked bit-for-bit against numpy 2.2.6, see tests/test_oracle.py)
+ *   mbo_escape     <- calc_mb_value, WorkerCUDA.py:39-68
+ *   mbo_quantise   <- process_workload, WorkerCUDA.py:96-98
+ *   mbo_view       <- gen_arrays' tile/repeat layout (WorkerCUDA.py:34-35) + the ufunc launch (:92)
+ *   mbo_datachunk  <- process_workload as a whole, WorkerCUDA.py:70-100
+ *
+ * Parity pinning: the reference has no tests and no golden vectors.
+ * The restatement is pinned instead against the reference's OWN Python source executed under
+ * CPython (numba replaced by a scalar shim): tests/golden/make_golden.py writes
+ * tests/golden/reference_vectors.npz.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MBO_MIN_AXIS (-2.0) /* WorkerCUDA.py:7, DataChunk.cs:14 */
+#define MBO_MAX_AXIS (2.0)  /* WorkerCUDA.py:8, DataChunk.cs:15 */
+
+/* WorkerCUDA.py:75-78.  Python: chunk_range = (MAX_AXIS - MIN_AXIS) / level  (int/int true
+ * division -> double); start = MIN_AXIS + (chunk_range * index). */
+void mbo_geometry(uint32_t level, uint32_t index_real, uint32_t index_imag,
+                  double *start_r, double *start_i, double *range)
+{
+    volatile double chunk_range = (MBO_MAX_AXIS - MBO_MIN_AXIS) / (double)level;
+    volatile double pr = chunk_range * (double)index_real;
+    volatile double pi = chunk_range * (double)index_imag;
+    *range = chunk_range;
+    *start_r = MBO_MIN_AXIS + pr;
+    *start_i = MBO_MIN_AXIS + pi;
+}
+
+/* np.linspace(start, start + range, num=n) as called at WorkerCUDA.py:24-32 (endpoint=True).
+ * numpy: div = n-1; delta = stop - start; y = arange(n) as double; step = delta/div;
+ *        if step == 0: y = (y/div)*delta  else: y = y*step;  y += start;  y[-1] = stop (n>1). */
+void mbo_axis(double start, double range, uint32_t n, double *out)
+{
+    if (n == 0) return;
+    volatile double stop = start + range;
+    if (n == 1) { out[0] = start; return; }
+    volatile double delta = stop - start;
+    double div = (double)(n - 1);
+    volatile double step = delta / div;
+    for (uint32_t k = 0; k + 1 < n; ++k) {
+        volatile double y;
+        if (step == 0.0) {
+            volatile double q = (double)k / div;
+            y = q * delta;
+        } else {
+            y = (double)k * step;
+        }
+        out[k] = y + start;
+    }
+    out[n - 1] = stop;
+}
+
+/* calc_mb_value, WorkerCUDA.py:39-68.  z starts at c (:45); for i in range(1, mrd) (:47):
+ * z = (z0*z0 - z1*z1, 2*z0*z1) (:50-53); z += c (:56-59); sqr_mag = z0*z0 + z1*z1 (:62);
+ * if sqr_mag >= 4 return i (:65-66); return 0 (:68).
+ * Written exactly as the source groups it: (2*z0)*z1, left to right. */
+int32_t mbo_escape(double cr, double ci, int32_t mrd)
+{
+    double zr = cr, zi = ci;
+    for (int32_t n = 1; n < mrd; ++n) {
+        double a = zr * zr;
+        double b = zi * zi;
+        double t = a - b;
+        double w = 2.0 * zr;
+        double u = w * zi;
+        zr = t + cr;
+        zi = u + ci;
+        double m0 = zr * zr;
+        double m1 = zi * zi;
+        double m = m0 + m1;
+        if (m >= 4.0) return n;
+    }
+    return 0;
+}
+
+/* WorkerCUDA.py:96-98: out = (out.astype(float64) * 256) / mrd; ceil(out).astype(uint8).
+ * 256.0 wraps to 0 (numpy's C cast on x86-64).  mrd == 0 would be 0/0 = NaN -> 0. */
+uint8_t mbo_quantise(int32_t count, uint32_t mrd)
+{
+    if (mrd == 0) return 0;
+    volatile double x = (double)count * 256.0;
+    volatile double q = x / (double)mrd;
+    return (uint8_t)(int64_t)ceil(q);
+}
+
+/*
+ * One rectangular window [row0,row0+nrows) x [col0,col0+ncols) of a width x height view whose
+ * axes are linspace(start_r, start_r+range_r, width) / linspace(start_i, start_i+range_i, height).
+ * Output element (row-row0)*ncols + (col-col0): real is the fast axis (np.tile, WorkerCUDA.py:34),
+ * imaginary the slow one (np.repeat, :35).  Either output pointer may be NULL.
+ * Returns the number of pixel-iterations executed (count if count>0 else max(mrd-1,0)).
+ */
+uint64_t mbo_view(double start_r, double start_i, double range_r, double range_i,
+                  uint32_t width, uint32_t height,
+                  uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
+                  int32_t mrd, int32_t *counts, uint8_t *bytes, int nthreads)
+{
+    double *xr = (double *)malloc(sizeof(double) * (width ? width : 1));
+    double *xi = (double *)malloc(sizeof(double) * (height ? height : 1));
+    mbo_axis(start_r, range_r, width, xr);
+    mbo_axis(start_i, range_i, height, xi);
+    uint64_t total = 0;
+    int64_t cap = mrd > 1 ? (int64_t)mrd - 1 : 0;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : total)
+#else
+    (void)nthreads;
+#endif
+    for (int64_t r = 0; r < (int64_t)nrows; ++r) {
+        double ci = xi[row0 + r];
+        uint64_t acc = 0;
+        for (uint32_t c = 0; c < ncols; ++c) {
+            int32_t cnt = mbo_escape(xr[col0 + c], ci, mrd);
+            size_t o = (size_t)r * ncols + c;
+            if (counts) counts[o] = cnt;
+            if (bytes) bytes[o] = mbo_quantise(cnt, (uint32_t)mrd);
+            acc += cnt > 0 ? (uint64_t)cnt : (uint64_t)cap;
+        }
+        total += acc;
+    }
+    free(xr);
+    free(xi);
+    return total;
+}
+
+/* process_workload, WorkerCUDA.py:70-100: one 4096 x 4096 DataChunk tile. */
+uint64_t mbo_datachunk(uint32_t level, uint32_t mrd, uint32_t index_real, uint32_t index_imag,
+                       int32_t *counts, uint8_t *bytes, int nthreads)
+{
+    double sr, si, range;
+    mbo_geometry(level, index_real, index_imag, &sr, &si, &range);
+    return mbo_view(sr, si, range, range, 4096, 4096, 0, 0, 4096, 4096, (int32_t)mrd, counts,
+                    bytes, nthreads);
+}
+
+int mbo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

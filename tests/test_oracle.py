@@ -1,0 +1,131 @@
+"""CPU tests of the oracle itself: before the oracle judges the GPU it is pinned against
+(1) vectors produced by EXECUTING the reference's own Python source (tests/golden/make_golden.py),
+(2) an independent numpy restatement, (3) numpy.linspace itself, (4) hand-checked points."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle.oracle import (numpy_axis, numpy_escape, numpy_geometry, numpy_quantise, numpy_view,
+                           pixel_iterations)
+
+
+def test_golden_small_windows_match_c_oracle(oracle, golden):
+    for name in golden["small/names"]:
+        sr, si, rng, n, mrd = golden[f"small/{name}/params"]
+        n, mrd = int(n), int(mrd)
+        counts, _, total = oracle.view(sr, si, rng, rng, n, n, mrd, want_bytes=mrd > 0)
+        ref = golden[f"small/{name}/counts"]
+        assert np.array_equal(counts, ref), name
+        assert total == pixel_iterations(ref, mrd), name
+        # the reference's own coordinate arrays (np.linspace inside gen_arrays)
+        assert np.array_equal(oracle.axis(sr, rng, n), golden[f"small/{name}/axis_r"]), name
+        assert np.array_equal(oracle.axis(si, rng, n), golden[f"small/{name}/axis_i"]), name
+
+
+def test_golden_points_match_c_oracle(oracle, golden):
+    for (cr, ci, mrd), ref in zip(golden["points/inputs"], golden["points/counts"]):
+        assert oracle.escape(cr, ci, int(mrd)) == int(ref), (cr, ci, mrd)
+
+
+def test_hand_checked_points(oracle):
+    # c = 0 never escapes; c = -2: z1 = 4-2 = 2, |z|^2 = 4 -> escapes at 1 under '>=' (WorkerCUDA.py:65);
+    # c = 2+2i: |z1|^2 huge -> 1; mrd <= 1 -> range(1, mrd) is empty -> 0.
+    assert oracle.escape(0.0, 0.0, 1000) == 0
+    assert oracle.escape(-2.0, 0.0, 1000) == 1
+    assert oracle.escape(2.0, 2.0, 1000) == 1
+    assert oracle.escape(-2.0, 0.0, 1) == 0
+    assert oracle.escape(-2.0, 0.0, 0) == 0
+    assert oracle.escape(-2.0, 0.0, 2) == 1
+    assert oracle.escape(0.25, 0.0, 100000) == 0      # parabolic point: never reaches 4
+    assert oracle.escape(0.26, 0.0, 1000) == 29
+
+
+def test_golden_full_tiles_match_c_oracle(oracle, golden):
+    """Full 4096x4096 tiles produced by the reference's unmodified process_workload."""
+    for key in golden["full/names"]:
+        level, mrd, ir, ii = (int(x) for x in golden[f"full/{key}/params"])
+        counts, byts, total = oracle.datachunk(level, mrd, ir, ii)
+        assert hashlib.sha256(byts.tobytes()).hexdigest() == str(golden[f"full/{key}/bytes_sha256"]), key
+        assert hashlib.sha256(counts.astype("<i4").tobytes()).hexdigest() == \
+            str(golden[f"full/{key}/counts_sha256"]), key
+        assert np.array_equal(byts[::64, ::64], golden[f"full/{key}/bytes_sub64"])
+        assert np.array_equal(counts[::64, ::64], golden[f"full/{key}/counts_sub64"])
+        assert int((counts == 0).sum()) == int(golden[f"full/{key}/zeros"])
+
+
+@pytest.mark.parametrize("level,ir,ii", [(1, 0, 0), (3, 1, 2), (4, 1, 2), (7, 6, 0), (10, 3, 5),
+                                          (20, 7, 9), (20, 19, 19), (800000, 251270, 426364),
+                                          (4294967295, 4294967294, 1)])
+def test_geometry_and_axis_match_python_and_numpy(oracle, level, ir, ii):
+    sr, si, rng = oracle.geometry(level, ir, ii)
+    assert (sr, si, rng) == numpy_geometry(level, ir, ii)
+    for start in (sr, si):
+        assert np.array_equal(oracle.axis(start, rng, 4096), np.linspace(start, start + rng, 4096))
+    # the last sample is the stop value start+range itself (endpoint=True), so adjacent tiles share
+    # their edge column/row up to the rounding of start+range
+    assert oracle.axis(sr, rng, 4096)[-1] == sr + rng
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 64, 513, 4096, 8192])
+def test_axis_matches_linspace_generic(oracle, n):
+    rs = np.random.RandomState(n)
+    for _ in range(20):
+        start = float(rs.uniform(-2, 2))
+        rng = float(10.0 ** rs.uniform(-12, 0.6))
+        assert np.array_equal(oracle.axis(start, rng, n), numpy_axis(start, rng, n))
+    # numpy's step == 0 fallback (range so small that step underflows to zero / delta == 0)
+    assert np.array_equal(oracle.axis(1.0, 0.0, n), numpy_axis(1.0, 0.0, n))
+    assert np.array_equal(oracle.axis(0.0, 5e-324, n), numpy_axis(0.0, 5e-324, n))
+
+
+def test_c_oracle_matches_numpy_oracle_on_seeded_views(oracle):
+    rs = np.random.RandomState(1234)
+    cases = [(-2.0, -1.5, 3.0, 3.0, 96, 80, 256), (-0.743648, 0.131820, 1e-5, 1e-5, 40, 40, 3000)]
+    for _ in range(6):
+        cr, ci = rs.uniform(-1.6, 0.4), rs.uniform(-1.1, 1.1)
+        span = 10.0 ** rs.uniform(-6, 0)
+        cases.append((cr, ci, span, span * rs.uniform(0.5, 2), int(rs.randint(1, 90)),
+                      int(rs.randint(1, 90)), int(rs.randint(1, 700))))
+    for sr, si, rr, ri, w, h, mrd in cases:
+        c, b, total = oracle.view(sr, si, rr, ri, w, h, mrd)
+        c2, b2 = numpy_view(sr, si, rr, ri, w, h, mrd)
+        assert np.array_equal(c, c2) and np.array_equal(b, b2)
+        assert total == pixel_iterations(c, mrd)
+        # windows are bit-identical to the corresponding slice of the whole view
+        if w > 3 and h > 3:
+            win = (1, 2, w - 2, h - 3)
+            cw, bw, _ = oracle.view(sr, si, rr, ri, w, h, mrd, window=win)
+            assert np.array_equal(cw, c[2:2 + h - 3, 1:1 + w - 2]) and np.array_equal(bw, b[2:2 + h - 3, 1:1 + w - 2])
+
+
+@pytest.mark.parametrize("mrd", [1, 2, 3, 255, 256, 257, 1000, 1024, 4095, 10000, 65535, 1000003])
+def test_quantiser_integer_form(oracle, mrd):
+    """WorkerCUDA.py:96-98 (float ceil + uint8 wrap) == ((count*256 + mrd-1) // mrd) & 0xFF, the form
+    the GPU kernel uses, for every legal count."""
+    counts = np.arange(0, mrd, dtype=np.int64)
+    if mrd > 70000:
+        rs = np.random.RandomState(mrd)
+        counts = np.unique(np.concatenate([counts[:3000], counts[-3000:], rs.randint(0, mrd, 50000)]))
+    ref = numpy_quantise(counts.astype(np.int32), mrd)
+    integer = (((counts * 256 + mrd - 1) // mrd) & 0xFF).astype(np.uint8)
+    assert np.array_equal(ref, integer)
+    sample = counts[:: max(1, len(counts) // 500)]
+    assert [oracle.quantise(int(c), mrd) for c in sample] == [int(x) for x in integer[:: max(1, len(counts) // 500)]]
+
+
+def test_quantiser_wrap_examples(oracle):
+    # for mrd = 1000 counts 997..999 wrap to byte 0
+    assert [oracle.quantise(c, 1000) for c in (0, 1, 3, 4, 996, 997, 999)] == [0, 1, 1, 2, 255, 0, 0]
+    # huge mrd (64-bit path on the GPU)
+    for mrd in (2 ** 23, 2 ** 24 + 1, 2 ** 31 - 1):
+        for c in (0, 1, mrd // 3, mrd - 2, mrd - 1):
+            assert oracle.quantise(c, mrd) == ((c * 256 + mrd - 1) // mrd) & 0xFF
+
+
+def test_numpy_escape_matches_scalar(oracle):
+    rs = np.random.RandomState(7)
+    cr = rs.uniform(-2, 0.6, 300)
+    ci = rs.uniform(-1.2, 1.2, 300)
+    v = numpy_escape(cr, ci, 400)
+    assert [oracle.escape(a, b, 400) for a, b in zip(cr, ci)] == v.tolist()

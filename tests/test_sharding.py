@@ -1,0 +1,96 @@
+"""CPU tests of the multi-GPU sharding logic: row bands, the shared work queue with fake devices
+(backed by the oracle -- tests only), and the one-process-per-GPU path under gloo, world_size 2."""
+import os
+import subprocess
+import sys
+import json
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from distributedmandelbrot_amd import View
+from distributedmandelbrot_amd.device import TileStats
+from distributedmandelbrot_amd.sharding import Band, WorkQueue, make_bands, rank_bands, render_view
+
+
+class OracleDevice:
+    """MandelbrotDevice look-alike for CPU tests of the host logic."""
+
+    def __init__(self, oracle):
+        self.oracle = oracle
+        self.calls = 0
+
+    def compute_view(self, view, mrd, *, window=None, want_counts=True, want_bytes=True, kernel="default"):
+        self.calls += 1
+        c, b, total = self.oracle.view(view.start_r, view.start_i, view.range_r, view.range_i,
+                                       view.width, view.height, mrd, window=window, nthreads=1)
+        return (c if want_counts else None, b if want_bytes else None,
+                TileStats(0.0, 0.0, total, int((c == 0).sum()), False, False))
+
+
+def test_make_bands_cover_exactly():
+    bands = make_bands(1000, 128)
+    assert [b.nrows for b in bands] == [128] * 7 + [104]
+    assert bands[0] == Band(0, 0, 128) and sum(b.nrows for b in bands) == 1000
+    assert make_bands(5, 8) == [Band(0, 0, 5)]
+    with pytest.raises(ValueError):
+        make_bands(0, 8)
+
+
+def test_rank_bands_partition():
+    bands = make_bands(4096, 128)
+    for world in (1, 2, 3, 8):
+        parts = [rank_bands(bands, r, world) for r in range(world)]
+        flat = sorted(b.index for p in parts for b in p)
+        assert flat == list(range(len(bands)))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        rank_bands(bands, 2, 2)
+
+
+def test_work_queue_hands_out_each_item_once():
+    import threading
+    q = WorkQueue(range(1000))
+    got = [[] for _ in range(8)]
+
+    def run(i):
+        while True:
+            x = q.pop()
+            if x is None:
+                return
+            got[i].append(x)
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert sorted(x for g in got for x in g) == list(range(1000))
+
+
+def test_render_view_over_fake_devices_equals_whole_view(oracle):
+    view, mrd = View(-2.0, -1.5, 3.0, 3.0, 200, 150), 200
+    devs = [OracleDevice(oracle) for _ in range(3)]
+    c, b, per = render_view(devs, view, mrd, band_rows=16)
+    oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, 200, 150, mrd)
+    assert np.array_equal(c, oc) and np.array_equal(b, ob)
+    assert sum(p["bands"] for p in per) == 10 and sum(p["pixel_iterations"] for p in per) == total
+    assert sum(d.calls for d in devs) == 10
+
+
+def test_bench_distributed_path_gloo_world2():
+    """bench.py's N>1 path (barrier, per-rank shard, max-over-ranks timing, aggregate) with two CPU
+    processes over gloo; the compute is a stub (MBK_BENCH_FAKE=1) because there is no GPU here."""
+    env = dict(os.environ, MBK_BENCH_FAKE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["data"].startswith("synthetic") and rec["higher_is_better"] is True
+    # fake backend: every rank reports 1e9 pixel-iterations per step -> aggregate = 2e9 * steps / time
+    assert rec["config"]["fake_backend"] is True
+    assert abs(rec["value"] - 2 * 1.0 * 3 / (rec["ms_per_step"] * 3 / 1e3)) / rec["value"] < 1e-6

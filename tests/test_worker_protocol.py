@@ -1,0 +1,141 @@
+"""CPU integration tests of the worker's wire protocol against a Python restatement of the
+reference's Distributer (tests/fake_distributer.py).  The compute function is injected (the product
+default is the HIP path, which has no CPU fallback); here it is the CPU oracle or a pattern."""
+import socket
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+from distributedmandelbrot_amd import worker
+from fake_distributer import CHUNK_BYTES, FakeDistributer
+
+QUIET = lambda *a: None  # noqa: E731
+
+
+def pattern_compute(level, mrd, ir, ii):
+    out = np.empty(CHUNK_BYTES, np.uint8)
+    out[:] = (np.arange(CHUNK_BYTES, dtype=np.uint32) * 2654435761 >> 13).astype(np.uint8)
+    out[:16] = np.frombuffer(struct.pack("<IIII", level, mrd, ir, ii), np.uint8)
+    return out
+
+
+def test_constants_match_reference():
+    # WorkerCUDA.py:7-17, Program.cs:13, DataChunk.cs:20,27
+    assert (worker.REQUEST_CODE, worker.RESPONSE_CODE) == (0x00, 0x01)
+    assert (worker.WORKLOAD_AVAILABLE_CODE, worker.WORKLOAD_NOT_AVAILABLE_CODE) == (0x10, 0x11)
+    assert (worker.WORKLOAD_ACCEPT_CODE, worker.WORKLOAD_REJECT_CODE) == (0x20, 0x21)
+    assert worker.DEFAULT_DISTRIBUTER_PORT == 59010 and worker.CHUNK_BYTES == 16777216
+    assert (worker.MIN_AXIS, worker.MAX_AXIS) == (-2, 2)
+
+
+def test_single_tile_roundtrip_with_oracle_compute(oracle):
+    def oracle_compute(level, mrd, ir, ii):
+        return oracle.datachunk(level, mrd, ir, ii, want_counts=False)[1].ravel()
+
+    with FakeDistributer([(1, 64)]) as srv:
+        assert worker.do_workload_single("127.0.0.1", srv.port, compute=oracle_compute, log=QUIET) is True
+        assert worker.do_workload_single("127.0.0.1", srv.port, compute=oracle_compute, log=QUIET) is False
+        (w, data), = srv.completed.items()
+        assert w == (1, 64, 0, 0)
+        assert np.array_equal(data, oracle_compute(1, 64, 0, 0))
+        assert not srv.leases
+
+
+def test_scan_order_and_all_tiles_completed():
+    # level 2 -> 4 tiles handed out indexReal-major, indexImag-minor (Distributer.cs:338-340)
+    with FakeDistributer([(2, 16), (1, 8)]) as srv:
+        order = []
+
+        def compute(level, mrd, ir, ii):
+            order.append((level, mrd, ir, ii))
+            return pattern_compute(level, mrd, ir, ii)
+
+        n = 0
+        while worker.do_workload_single("127.0.0.1", srv.port, compute=compute, log=QUIET):
+            n += 1
+        assert n == 5
+        assert order == [(2, 16, 0, 0), (2, 16, 0, 1), (2, 16, 1, 0), (2, 16, 1, 1), (1, 8, 0, 0)]
+        for w, data in srv.completed.items():
+            assert np.array_equal(data, pattern_compute(*w))
+
+
+def test_rejected_result_returns_true_and_tile_is_reissued():
+    with FakeDistributer([(1, 32)]) as srv:
+        def slow_compute(level, mrd, ir, ii):
+            srv.expire_all_leases()  # the lease times out while we compute (Distributer.cs:22,153-160)
+            return pattern_compute(level, mrd, ir, ii)
+
+        # reject -> the reference returns True and carries on (WorkerCUDA.py:161-163)
+        assert worker.do_workload_single("127.0.0.1", srv.port, compute=slow_compute, log=QUIET) is True
+        assert srv.rejected == [(1, 32, 0, 0)] and not srv.completed
+        # the expired tile is offered again and now completes
+        assert worker.do_workload_single("127.0.0.1", srv.port, compute=pattern_compute, log=QUIET) is True
+        assert srv.wait_completed(1)
+        assert list(srv.completed) == [(1, 32, 0, 0)]
+
+
+def _one_shot_server(reply: bytes):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    s.listen(1)
+
+    def run():
+        c, _ = s.accept()
+        c.recv(1)
+        c.sendall(reply)
+        c.close()
+        s.close()
+
+    threading.Thread(target=run, daemon=True).start()
+    return s.getsockname()[1]
+
+
+def test_unknown_opcode_raises_like_the_reference():
+    port = _one_shot_server(bytes([0x7F]))
+    with pytest.raises(Exception, match="Unknown response code to request: 127"):
+        worker.do_workload_single("127.0.0.1", port, compute=pattern_compute, log=QUIET)
+
+
+def test_short_header_is_an_error_not_garbage():
+    port = _one_shot_server(bytes([0x10, 1, 0]))  # workload header cut short
+    with pytest.raises(ConnectionError):
+        worker.request_workload("127.0.0.1", port)
+
+
+def test_payload_size_is_enforced():
+    with pytest.raises(ValueError):
+        worker.submit_workload("127.0.0.1", 1, (1, 1, 0, 0), np.zeros(100, np.uint8))
+
+
+def test_farm_two_feeders_complete_every_tile_once():
+    with FakeDistributer([(3, 16)]) as srv:
+        seen = []
+        lock = threading.Lock()
+
+        def make_compute(dev):
+            def compute(level, mrd, ir, ii):
+                with lock:
+                    seen.append((dev, (level, mrd, ir, ii)))
+                return pattern_compute(level, mrd, ir, ii)
+            return compute
+
+        done = worker.run_farm("127.0.0.1", srv.port, devices=[0, 1], make_compute=make_compute, log=QUIET)
+        assert srv.wait_completed(9)
+        assert sum(done) == 9 and len(srv.completed) == 9
+        assert sorted(w for _, w in seen) == sorted(srv.completed)
+        assert len({w for _, w in seen}) == 9  # no tile computed twice
+        for w, data in srv.completed.items():
+            assert np.array_equal(data, pattern_compute(*w))
+
+
+def test_reference_faithful_single_receive_mode_documents_the_defect():
+    # Distributer.cs:416 reads the 16 MiB with ONE Receive; our worker still sends all of it.
+    with FakeDistributer([(1, 8)], faithful_single_receive=True) as srv:
+        assert worker.do_workload_single("127.0.0.1", srv.port, compute=pattern_compute, log=QUIET)
+        assert srv.wait_completed(1)
+        (w, data), = srv.completed.items()
+        got = int([l for l in srv.log if l.startswith("single receive")][0].split()[3])
+        assert 0 < got <= CHUNK_BYTES
+        assert np.array_equal(data[:got], pattern_compute(*w)[:got])
