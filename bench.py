@@ -42,6 +42,9 @@ WORKLOADS = {
     "cfg3": (-0.743648, 0.131820, 1e-5, 8192, 8192, 10000,
              "8192x8192 deep zoom (centre -0.743643+0.131825i, span 1e-5), mrd 10000"),
     "chunk_l1": (-2.0, -2.0, 4.0, 4096, 4096, 1000, "DataChunk (level 1, 0, 0) = [-2,2]^2, mrd 1000"),
+    # diagnostics (not BASELINE configs): uniform all-in-set tile = pure loop throughput, no divergence
+    "inset": (-0.2, -0.1, 0.2, 4096, 4096, 1000, "4096x4096 inside the main cardioid (every pixel runs mrd-1 steps)"),
+    "exterior": (-2.0, -2.0, 1.0, 4096, 4096, 1000, "DataChunk (4,0,0): every pixel escapes within 3 steps"),
 }
 FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
 VALU_OPS_PER_PIXEL_ITER = 7     # 3 mul + 3 add + 1 fma(2, p, ci)  (contraction-free stream)

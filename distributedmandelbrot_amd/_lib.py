@@ -7,7 +7,9 @@ If it is missing the import of the product path FAILS LOUDLY -- there is no CPU 
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libmbk_hip.so")
@@ -72,6 +74,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever
+    copy is loaded first serves the whole process; torch fails with "No HIP GPUs are available" when
+    the system copy got in first.  So: if torch is installed but not imported yet, pre-load ITS copy
+    (cheap -- torch itself is not imported) so that either import order works.  Opt out with
+    MBK_HIP_RUNTIME=system."""
+    if os.environ.get("MBK_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load libmbk_hip.so and declare every entry point.  Raises if the library is not built."""
     global _lib
@@ -81,6 +105,7 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{SO_PATH} is missing: build it with `python -m distributedmandelbrot_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(SO_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -150,6 +150,16 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     const uint32_t kernel = flags & MBK_KERNEL_MASK;
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
+        case MBK_KERNEL_ASM: {
+            a.blocks_x = (v->ncols + 31u) / 32u;
+            const uint32_t by = (v->nrows + 7u) / 8u;
+            const dim3 grid(a.blocks_x * by), block(256);
+            if (safe)
+                hipLaunchKernelGGL(mbk::tile_asm_kernel<false>, grid, block, 0, stream, a);
+            else
+                hipLaunchKernelGGL(mbk::tile_asm_kernel<true>, grid, block, 0, stream, a);
+            break;
+        }
         case MBK_KERNEL_SIMPLE: {
             a.blocks_x = (v->ncols + 31u) / 32u;
             const uint32_t by = (v->nrows + 7u) / 8u;
@@ -337,8 +347,7 @@ int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t f
 {
     if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
     MBK_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    return launch_tile(ctx, view, mrd, flags, d_counts, d_bytes, s);
+    return launch_tile(ctx, view, mrd, flags, d_counts, d_bytes, (hipStream_t)hip_stream);
 }
 
 int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
@@ -408,7 +417,7 @@ int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_
 {
     if (!ctx || !d_counts || !stats) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
     MBK_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t s = (hipStream_t)hip_stream;
     int rc = launch_reduce(ctx, d_counts, nullptr, n, mrd, s);
     if (rc != MBK_OK) return rc;
     MBK_HIP(ctx, hipStreamSynchronize(s));

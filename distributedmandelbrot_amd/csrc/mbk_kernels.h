@@ -126,6 +126,118 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel "asm": same pixel mapping as "simple", but the escape loop is a hand-scheduled gfx950
+// instruction stream.  Why: the compiler's structured-CFG loop spends ~14 SALU instructions and 3
+// branches per iteration on EXEC bookkeeping; a CU has ONE scalar pipe for its four SIMDs, so at 8
+// waves/SIMD the compiler loop is scalar-issue bound (measured 1.7 T pixel-iter/s, ~72 cycles per
+// wave-iteration) instead of fp64-VALU bound (7 x 4 cycles).  This loop issues, per iteration,
+// 7 fp64 VALU + 1 v_cmp + 1 branch, plus 3 SALU per FOUR iterations:
+//   * the iteration counter lives in an SGPR (uniform) and is bumped once per 4 unrolled steps;
+//   * "some lane escaped" is the rare path: `s_cbranch_vccnz` jumps out of line, where the escaped
+//     lanes record the step index and leave EXEC; when EXEC empties the wave leaves the loop at
+//     once (the wavefront-level early exit);
+//   * v_cmp_le_f64 vcc, 4.0, m implements `m >= 4` with IEEE semantics (false for NaN).
+// kFmaDouble = false swaps fma(2, zr*zi, ci) for the literal (zr+zr)*zi + ci (8 fp64 ops).
+// ---------------------------------------------------------------------------------------------
+#define MBK_STEP_HEAD_FMA                                  \
+    "v_add_f64 %[t], %[a], -%[b]\n"                        \
+    "v_mul_f64 %[p], %[zr], %[zi]\n"                       \
+    "v_add_f64 %[zr], %[t], %[cr]\n"                       \
+    "v_fma_f64 %[zi], %[p], 2.0, %[ci]\n"
+#define MBK_STEP_HEAD_SAFE                                 \
+    "v_add_f64 %[t], %[a], -%[b]\n"                        \
+    "v_add_f64 %[p], %[zr], %[zr]\n"                       \
+    "v_mul_f64 %[p], %[p], %[zi]\n"                        \
+    "v_add_f64 %[zr], %[t], %[cr]\n"                       \
+    "v_add_f64 %[zi], %[p], %[ci]\n"
+#define MBK_STEP_TAIL(ID)                                  \
+    "v_mul_f64 %[a], %[zr], %[zr]\n"                       \
+    "v_mul_f64 %[b], %[zi], %[zi]\n"                       \
+    "v_add_f64 %[m], %[a], %[b]\n"                         \
+    "v_cmp_le_f64 vcc, 4.0, %[m]\n"                        \
+    "s_cbranch_vccnz .Lesc" ID "_%=\n"                     \
+    ".Lcont" ID "_%=:\n"
+// out-of-line: lanes in VCC escaped at step N+INC
+#define MBK_ESCAPE(ID, INC)                                \
+    ".Lesc" ID "_%=:\n"                                    \
+    "s_add_u32 %[k], %[n], " INC "\n"                      \
+    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
+    "v_mov_b32 %[cnt], %[k]\n"                             \
+    "s_andn2_b64 exec, %[tmp], vcc\n"                      \
+    "s_cbranch_scc1 .Lcont" ID "_%=\n"                     \
+    "s_branch .Ldone_%=\n"
+#define MBK_LOOP_ASM(HEAD)                                 \
+    "s_mov_b64 %[save], exec\n"                            \
+    "s_mov_b32 %[n], 0\n"                                  \
+    "s_cmp_eq_u32 %[limit4], 0\n"                          \
+    "s_cbranch_scc1 .Ltail_%=\n"                           \
+    ".Lmain_%=:\n"                                         \
+    HEAD MBK_STEP_TAIL("1") HEAD MBK_STEP_TAIL("2")        \
+    HEAD MBK_STEP_TAIL("3") HEAD MBK_STEP_TAIL("4")        \
+    "s_add_u32 %[n], %[n], 4\n"                            \
+    "s_cmp_lt_u32 %[n], %[limit4]\n"                       \
+    "s_cbranch_scc1 .Lmain_%=\n"                           \
+    ".Ltail_%=:\n"                                         \
+    "s_cmp_ge_u32 %[n], %[total]\n"                        \
+    "s_cbranch_scc1 .Ldone_%=\n"                           \
+    ".Ltloop_%=:\n"                                        \
+    HEAD MBK_STEP_TAIL("T")                                \
+    "s_add_u32 %[n], %[n], 1\n"                            \
+    "s_cmp_lt_u32 %[n], %[total]\n"                        \
+    "s_cbranch_scc1 .Ltloop_%=\n"                          \
+    "s_branch .Ldone_%=\n"                                 \
+    MBK_ESCAPE("1", "1") MBK_ESCAPE("2", "2") MBK_ESCAPE("3", "3") MBK_ESCAPE("4", "4")  \
+    MBK_ESCAPE("T", "1")                                   \
+    ".Ldone_%=:\n"                                         \
+    "s_mov_b64 exec, %[save]\n"
+
+template <bool kFmaDouble>
+__device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_t mrd)
+{
+    double zr = cr, zi = ci;
+    double a = zr * zr, b = zi * zi;
+    double t, p, m;
+    int32_t cnt = 0;
+    const uint32_t total = mrd > 1 ? (uint32_t)mrd - 1u : 0u;  // number of z updates (uniform)
+    const uint32_t limit4 = total & ~3u;
+    uint32_t n, k;
+    unsigned long long save, tmp;
+    if (kFmaDouble) {
+        asm volatile(MBK_LOOP_ASM(MBK_STEP_HEAD_FMA)
+                     : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
+                       [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
+                       [save] "=&s"(save), [tmp] "=&s"(tmp)
+                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4)
+                     : "vcc", "scc");
+    } else {
+        asm volatile(MBK_LOOP_ASM(MBK_STEP_HEAD_SAFE)
+                     : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
+                       [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
+                       [save] "=&s"(save), [tmp] "=&s"(tmp)
+                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4)
+                     : "vcc", "scc");
+    }
+    return cnt;
+}
+
+template <bool kFmaDouble>
+__global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t by = blockIdx.x / p.blocks_x, bx = blockIdx.x - by * p.blocks_x;
+    const uint32_t lc = bx * 32u + wave * 8u + (lane & 7u);
+    const uint32_t lr = by * 8u + (lane >> 3);
+    if (lc >= p.ncols || lr >= p.nrows) return;
+    const double cr = axis_value(p.re, p.col0 + lc);
+    const double ci = axis_value(p.im, p.row0 + lr);
+    const int32_t count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd);
+    const size_t o = (size_t)lr * p.ncols + lc;
+    if (p.counts) p.counts[o] = count;
+    if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Reduction over finished results: pixel-iterations, never-escaped pixels, all-zero / all-one byte
 // flags (DataChunk.cs:82,87).  HBM-bound, 4-5 B/pixel read once; not part of the timed hot loop.
 // ---------------------------------------------------------------------------------------------

@@ -169,7 +169,7 @@ class MandelbrotDevice:
     def launch_view(self, view: View, mrd: int, *, d_counts: int = 0, d_bytes: int = 0,
                     stream: int = 0, window=None, kernel: str = "default") -> None:
         """Asynchronous launch on raw DEVICE pointers (e.g. torch tensors' data_ptr()) on ``stream``
-        (a hipStream_t as int; 0 = the context's own stream)."""
+        (a hipStream_t as int; 0 = HIP's null stream, which is also torch's default stream)."""
         cv = self._cview(view, window)
         flags = L.KERNELS[kernel] | (L.MBK_WANT_COUNTS if d_counts else 0) | (L.MBK_WANT_BYTES if d_bytes else 0)
         self._check(self._lib.mbk_view_launch(self._h, C.byref(cv), mrd, flags,

@@ -117,7 +117,8 @@ int mbk_datachunk_geometry(uint32_t level, uint32_t index_real, uint32_t index_i
                            double *start_r, double *start_i, double *range);
 
 /*
- * Asynchronous launch on DEVICE pointers, on the caller's HIP stream (NULL = the ctx's own stream).
+ * Asynchronous launch on DEVICE pointers, on the caller's HIP stream (a hipStream_t; NULL = HIP's null
+ * stream, which is what PyTorch's default stream is -- NOT the ctx's private stream).
  * Replaces gen_arrays (WorkerCUDA.py:19-37: coordinates are generated in-kernel), the two H2D copies
  * (:87-88), the ufunc launch `calc_mb_value(r_device, i_device, mrd, out=out_device)` (:92) and,
  * with MBK_WANT_BYTES, the host quantiser (:96-98).  d_counts: int32[nrows*ncols] (or NULL without
@@ -139,8 +140,8 @@ int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t 
 int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_real,
                   uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, mbk_stats *stats);
 
-/* Device-side reduction over int32 counts already in HBM (asynchronous part on hip_stream, then a
- * stream sync): fills stats->pixel_iterations and stats->never_pixels.  Used by bench.py to turn
+/* Device-side reduction over int32 counts already in HBM (asynchronous part on hip_stream -- NULL =
+ * the null stream -- then a stream sync): fills stats->pixel_iterations and stats->never_pixels.  Used by bench.py to turn
  * kernel time into pixel-iterations/s from the kernel's own output. */
 int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_t mrd,
                       void *hip_stream, mbk_stats *stats);
