@@ -86,6 +86,21 @@ def cpu_baseline(workload):
             "seconds": dt}
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass of this same command
+    (profiles/r01/cfg2_default_pmc_summary.json: WRITE_SIZE and FETCH_SIZE are in KiB; FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None for un-profiled combinations -- PMC
+    counters cannot be collected from inside the timed run itself."""
+    if workload != "cfg2" or kernel not in ("default", "asm"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "cfg2_default_pmc_summary.json")) as f:
+            pmc = json.load(f)
+        return int(pmc["WRITE_SIZE"]["mean"] * 1024 + 2 * pmc["FETCH_SIZE"]["mean"] * 1024)
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -213,7 +228,7 @@ def main():
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak_tflops,
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload, args.kernel),
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_ms_min": min(kernel_ms),
                 "flops_per_pixel_iteration": FLOPS_PER_PIXEL_ITER,

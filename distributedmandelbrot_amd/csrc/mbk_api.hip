@@ -10,15 +10,20 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 
 #include "mbk_kernels.h"
+#include "mbk_refill.h"
 
 using mbk::Axis;
 using mbk::ReduceOut;
 using mbk::TileArgs;
+using mbk::WorkQueues;
+
+static const int kQueueRing = 8;  // launches in flight on one ctx may overlap by this many
 
 struct mbk_ctx {
     int device = -1;
@@ -29,6 +34,9 @@ struct mbk_ctx {
     size_t cap_px = 0;
     ReduceOut *d_red = nullptr;
     ReduceOut *h_red = nullptr;  // pinned
+    WorkQueues *d_queues = nullptr;  // kQueueRing work-queue blocks for the persistent kernel
+    unsigned queue_turn = 0;
+    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 0, waves_per_wg = 1;  // tunables (MBK_* env)
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -98,6 +106,24 @@ static const double kMaxCoord = 0x1p500;
 // exactly 0) rules that out; otherwise use the literal (2*zr)*zi instantiation.
 static const double kSafeImagMin = 0x1p-900;
 
+// A multiplier coprime to n near n * (golden ratio - 1): id -> (id * m) mod n is a bijection that
+// sends neighbouring ids far apart.
+static uint32_t coprime_multiplier(uint32_t n)
+{
+    if (n < 4) return 1u;
+    uint64_t m = (uint64_t)((double)n * 0.6180339887498949);
+    if (m < 1) m = 1;
+    for (;; ++m) {
+        uint64_t a = m, b = n;
+        while (b) {
+            const uint64_t t = a % b;
+            a = b;
+            b = t;
+        }
+        if (a == 1) return (uint32_t)(m % n);
+    }
+}
+
 static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling)
 {
     if (!v) return fail(ctx, MBK_ERR_INVALID, "view is NULL");
@@ -144,6 +170,10 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     a.nrows = v->nrows;
     a.mrd = (int32_t)mrd;
     a.quant_wide = (mrd >= (1u << 23)) ? 1u : 0u;
+    a.rf_livemin = ctx->rf_livemin;
+    a.rf_patience = ctx->rf_patience;
+    a.rf_batch = ctx->rf_batch;
+    a.perm_mul = 1u;
     a.counts = wc ? d_counts : nullptr;
     a.bytes = wb ? d_bytes : nullptr;
 
@@ -151,13 +181,34 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
         case MBK_KERNEL_ASM: {
-            a.blocks_x = (v->ncols + 31u) / 32u;
+            const uint32_t wpw = ctx->waves_per_wg;  // 8x8-pixel blocks (= waves) per workgroup
+            a.blocks_x = (v->ncols + 8u * wpw - 1u) / (8u * wpw);
             const uint32_t by = (v->nrows + 7u) / 8u;
-            const dim3 grid(a.blocks_x * by), block(256);
+            const dim3 grid(a.blocks_x * by), block(64u * wpw);
+            a.perm_mul = ctx->order ? coprime_multiplier(grid.x) : 1u;
             if (safe)
                 hipLaunchKernelGGL(mbk::tile_asm_kernel<false>, grid, block, 0, stream, a);
             else
                 hipLaunchKernelGGL(mbk::tile_asm_kernel<true>, grid, block, 0, stream, a);
+            break;
+        }
+        case MBK_KERNEL_REFILL: {
+            if (mrd < 2) {  // nothing to iterate: the plain kernel writes the zeros
+                a.blocks_x = (v->ncols + 31u) / 32u;
+                const dim3 grid(a.blocks_x * ((v->nrows + 7u) / 8u)), block(256);
+                hipLaunchKernelGGL(mbk::tile_asm_kernel<true>, grid, block, 0, stream, a);
+                break;
+            }
+            const uint32_t nblocks = ((v->ncols + 7u) / 8u) * ((v->nrows + 7u) / 8u);
+            WorkQueues *wq = ctx->d_queues + (ctx->queue_turn++ % kQueueRing);
+            hipLaunchKernelGGL(mbk::init_queues_kernel, dim3(1), dim3(64), 0, stream, wq, nblocks);
+            uint32_t waves = (uint32_t)ctx->prop.multiProcessorCount * 4u * ctx->rf_waves_per_simd;
+            if (waves > nblocks) waves = nblocks;
+            const dim3 grid((waves + 3u) / 4u), block(256);
+            if (safe)
+                hipLaunchKernelGGL(mbk::tile_refill_kernel<false>, grid, block, 0, stream, a, wq);
+            else
+                hipLaunchKernelGGL(mbk::tile_refill_kernel<true>, grid, block, 0, stream, a, wq);
             break;
         }
         case MBK_KERNEL_SIMPLE: {
@@ -247,6 +298,12 @@ int mbk_create(int device, mbk_ctx **out)
     mbk_ctx *ctx = new (std::nothrow) mbk_ctx();
     if (!ctx) return fail(nullptr, MBK_ERR_NOMEM, "out of host memory");
     ctx->device = device;
+    if (const char *e = std::getenv("MBK_RF_LIVEMIN")) ctx->rf_livemin = (unsigned)std::atoi(e);
+    if (const char *e = std::getenv("MBK_RF_PATIENCE")) ctx->rf_patience = (unsigned)std::atoi(e);
+    if (const char *e = std::getenv("MBK_WPW")) { unsigned w = (unsigned)std::atoi(e); if (w == 1 || w == 2 || w == 4) ctx->waves_per_wg = w; }
+    if (const char *e = std::getenv("MBK_ORDER")) ctx->order = (unsigned)std::atoi(e);
+    if (const char *e = std::getenv("MBK_RF_BATCH")) ctx->rf_batch = (unsigned)std::atoi(e) > 0 ? (unsigned)std::atoi(e) : 1u;
+    if (const char *e = std::getenv("MBK_RF_WAVES")) ctx->rf_waves_per_simd = (unsigned)std::atoi(e);
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
         hipError_t e2_ = (call);                                                    \
@@ -270,6 +327,7 @@ int mbk_create(int device, mbk_ctx **out)
     MBK_CREATE_HIP(hipEventCreate(&ctx->ev_c0));
     MBK_CREATE_HIP(hipEventCreate(&ctx->ev_c1));
     MBK_CREATE_HIP(hipMalloc((void **)&ctx->d_red, sizeof(ReduceOut)));
+    MBK_CREATE_HIP(hipMalloc((void **)&ctx->d_queues, sizeof(WorkQueues) * kQueueRing));
     MBK_CREATE_HIP(hipHostMalloc((void **)&ctx->h_red, sizeof(ReduceOut), hipHostMallocDefault));
 #undef MBK_CREATE_HIP
     *out = ctx;
@@ -284,6 +342,7 @@ void mbk_destroy(mbk_ctx *ctx)
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
     if (ctx->d_red) (void)hipFree(ctx->d_red);
+    if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);

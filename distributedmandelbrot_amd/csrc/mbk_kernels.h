@@ -41,6 +41,10 @@ struct TileArgs {
     uint32_t blocks_x;    // workgroups per row of 8-pixel-high block rows (1-D grid)
     int32_t mrd;
     uint32_t quant_wide;  // 1: count*256+mrd-1 does not fit 32 bits -> 64-bit quantiser division
+    uint32_t rf_livemin;  // refill kernel policy: leave the hot loop when <= this many lanes are live
+    uint32_t rf_patience; // ... or this many steps after the first unrefilled escape
+    uint32_t rf_batch;    // 8x8 blocks taken per queue pop
+    uint32_t perm_mul;    // workgroup order: block = (blockIdx * perm_mul) mod gridDim (1 = row-major)
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
 };
@@ -225,8 +229,12 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t by = blockIdx.x / p.blocks_x, bx = blockIdx.x - by * p.blocks_x;
-    const uint32_t lc = bx * 32u + wave * 8u + (lane & 7u);
+    // Dispatch order != image order: consecutive workgroup ids are scattered over the tile by a
+    // multiplicative permutation (perm_mul coprime to the grid size), so the long-running in-set
+    // blocks do not arrive in clusters.
+    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
+    const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
+    const uint32_t lc = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);  // one 8x8 block per wave
     const uint32_t lr = by * 8u + (lane >> 3);
     if (lc >= p.ncols || lr >= p.nrows) return;
     const double cr = axis_value(p.re, p.col0 + lc);

@@ -1,0 +1,289 @@
+// mbk_refill.h -- kernel "refill": persistent wavefronts with lane refill, for gfx950.
+//
+// Why (measured on MI355X, BASELINE cfg2): with one workgroup per 32x8 pixel block
+// the hand-scheduled loop reaches 4.4 T pixel-iter/s on a uniform all-in-set tile but only ~2.9 T on
+// cfg2: 83 % of the 65 536 workgroups are trivial (dispatch-bound), the heavy ones cluster in space
+// so the in-order dispatcher leaves SIMDs under-occupied (average 3.9 of 8 waves), lanes whose pixel
+// escaped idle until the slowest lane of their wave is done, and the last heavy workgroups drain on
+// an almost empty chip.  Here instead:
+//   * the grid is sized to fill the machine once (8 waves/SIMD) and every wave is a worker that
+//     lives until the tile is done -- no dispatch cost per block, no clustered tail;
+//   * pixels are handed out in 8x8 blocks from 64 small work queues in HBM (one atomicAdd per 64
+//     pixels, 64 addresses so no single counter is hot; a 64-bit "non-empty" mask lets a worker whose
+//     home queue ran dry find the remaining work in O(1)) -- this is the per-GPU dynamic work queue of
+//     the north star pushed down to wavefront granularity;
+//   * a lane whose pixel escaped is refilled with the next pixel of the wave's current block while
+//     the other lanes keep iterating: per-lane state is just (c, z, |z|^2 parts, start clock);
+//   * the iteration "clock" n is wave-uniform (SGPR); a lane's escape index is clock - start.
+// The hot loop is the same hand-scheduled stream as kernel "asm" (7 fp64 VALU + v_cmp + 1 branch per
+// step, 4 SALU per 4 steps); everything rare (retire, refill, queue pops, the mrd deadline) is plain
+// HIP C++ between two entries of the loop.
+//
+// Bit-exactness: identical arithmetic per pixel as the other kernels; only the ORDER in which pixels
+// are processed differs, and pixels are independent.  A lane may run up to 3 steps past mrd-1
+// (the deadline is checked at 4-step boundaries); an "escape" recorded past mrd-1 is reported as 0.
+#pragma once
+
+#include "mbk_kernels.h"
+
+namespace mbk {
+
+constexpr int kNumQueues = 64;
+constexpr uint32_t kNoBlock = 0xffffffffu;
+
+struct WorkQueues {  // 64-byte slots: each counter on its own cache line
+    struct Slot {
+        unsigned int next;
+        unsigned int pad[15];
+    } q[kNumQueues];
+};
+
+// queue t owns blocks [queue_lo(t), queue_lo(t+1)) -- pure arithmetic, so `end` is never loaded
+__device__ __forceinline__ uint32_t queue_lo(uint32_t nblocks, uint32_t t)
+{
+    return (uint32_t)(((uint64_t)nblocks * t) / kNumQueues);
+}
+
+// One block of 64 threads resets the 64 cursors (runs on the launch stream before the tile kernel).
+__global__ __launch_bounds__(64) void init_queues_kernel(WorkQueues *w, uint32_t nblocks)
+{
+    w->q[threadIdx.x].next = queue_lo(nblocks, threadIdx.x);
+}
+
+// Per-wave view of the queues: the queue it is currently draining and that queue's end.
+struct Popper {
+    uint32_t cq;      // current queue (wave-uniform)
+    uint32_t cq_end;  // its end
+};
+
+// Pop `want` consecutive 8x8 blocks for this wave: returns the first block id (or kNoBlock when the
+// whole tile has been handed out) and the number granted in *got.  All 64 lanes call it.
+// Fast path: ONE atomicAdd on the wave's current queue (64 addresses, ~128 customers each).
+// When that queue is dry: every lane loads one queue cursor (one vector load, 64 lines), the ballot
+// of "cursor < end" is a fresh non-empty mask, and the wave moves to the nearest non-empty queue.
+__device__ __forceinline__ uint32_t pop_blocks(WorkQueues *w, Popper &pp, uint32_t nblocks,
+                                               uint32_t home, uint32_t lane, uint32_t want,
+                                               uint32_t *got)
+{
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = atomicAdd(&w->q[pp.cq].next, want);
+        idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        if (idx < pp.cq_end) {
+            const uint32_t left = pp.cq_end - idx;
+            *got = left < want ? left : want;
+            return idx;
+        }
+        // current queue is dry: scan all cursors at once
+        const uint32_t nx = __hip_atomic_load(&w->q[lane].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long m = __ballot(nx < queue_lo(nblocks, lane + 1u));
+        if (m == 0) {
+            *got = 0;
+            return kNoBlock;
+        }
+        const unsigned long long rot = (m >> home) | (m << ((64u - home) & 63u));
+        pp.cq = (home + (uint32_t)__ffsll((long long)rot) - 1u) & 63u;
+        pp.cq_end = queue_lo(nblocks, pp.cq + 1u);
+    }
+}
+
+__device__ __forceinline__ uint32_t uniform_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+{
+    const uint32_t lo = uniform_u32((uint32_t)v), hi = uniform_u32((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// ---- the hot loop: runs the lanes in LIVE until an event needs the slow path ------------------
+// Leaves when (a) no lane is left, (b) at most LIVEMIN lanes are left (enough free lanes to make a
+// refill worthwhile), (c) the clock reaches ALARM at a 4-step boundary (ALARM = mrd deadline bound,
+// pulled in to "first unrefilled escape + PATIENCE").  Escaped lanes get CNT = clock - START.
+#define MBK_RF_STEP(ID)                                    \
+    "v_mul_f64 %[a], %[zr], %[zr]\n"                       \
+    "v_mul_f64 %[b], %[zi], %[zi]\n"                       \
+    "v_add_f64 %[m], %[a], %[b]\n"                         \
+    "v_cmp_le_f64 vcc, 4.0, %[m]\n"                        \
+    "s_cbranch_vccnz .Lresc" ID "_%=\n"                    \
+    ".Lrcont" ID "_%=:\n"
+#define MBK_RF_ESCAPE(ID, INC)                             \
+    ".Lresc" ID "_%=:\n"                                   \
+    "s_add_u32 %[k], %[n], " INC "\n"                      \
+    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
+    "v_sub_u32 %[cnt], %[k], %[start]\n"                   \
+    "s_andn2_b64 exec, %[tmp], vcc\n"                      \
+    "s_cbranch_scc0 .Lrmid_%=\n"                           \
+    "s_bcnt1_i32_b64 %[k2], exec\n"                        \
+    "s_cmp_le_u32 %[k2], %[livemin]\n"                     \
+    "s_cbranch_scc1 .Lrmid_%=\n"                           \
+    "s_add_u32 %[k2], %[k], %[patience]\n"                 \
+    "s_sub_u32 %[k3], %[k2], %[alarm]\n"                   \
+    "s_cmp_lt_i32 %[k3], 0\n"                              \
+    "s_cselect_b32 %[alarm], %[k2], %[alarm]\n"            \
+    "s_branch .Lrcont" ID "_%=\n"
+#define MBK_RF_LOOP(HEAD)                                  \
+    "s_mov_b64 %[save], exec\n"                            \
+    "s_mov_b64 exec, %[live]\n"                            \
+    ".Lrmain_%=:\n"                                        \
+    HEAD MBK_RF_STEP("1") HEAD MBK_RF_STEP("2")            \
+    HEAD MBK_RF_STEP("3") HEAD MBK_RF_STEP("4")            \
+    "s_add_u32 %[n], %[n], 4\n"                            \
+    "s_sub_u32 %[k3], %[n], %[alarm]\n"                    \
+    "s_cmp_lt_i32 %[k3], 0\n"                              \
+    "s_cbranch_scc1 .Lrmain_%=\n"                          \
+    "s_branch .Lrout_%=\n"                                 \
+    MBK_RF_ESCAPE("1", "1") MBK_RF_ESCAPE("2", "2")        \
+    MBK_RF_ESCAPE("3", "3") MBK_RF_ESCAPE("4", "4")        \
+    ".Lrmid_%=:\n"                                         \
+    "s_mov_b32 %[n], %[k]\n"                               \
+    ".Lrout_%=:\n"                                         \
+    "s_mov_b64 %[live], exec\n"                            \
+    "s_mov_b64 exec, %[save]\n"
+
+template <bool kFmaDouble>
+__global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues *wq)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t home = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u;
+    const uint32_t total = (uint32_t)p.mrd - 1u;  // host guarantees mrd >= 2
+    const uint32_t bxn = (p.ncols + 7u) / 8u;     // 8x8 blocks per block-row
+    constexpr uint32_t kFar = 0x40000000u;         // all relative clock offsets stay below 2^30
+
+    double cr = 0.0, ci = 0.0, zr = 0.0, zi = 0.0, a = 0.0, b = 0.0;
+    uint32_t start = 0, cnt = 0, opix = 0;
+    unsigned long long live = 0;  // wave-uniform: lanes with a pixel in flight
+    uint32_t n = 0;               // wave-uniform clock: steps executed by this wave so far
+    uint32_t bound = 0;           // lower bound on the earliest clock at which a live lane hits mrd-1
+    uint32_t blk = 0, blk_pos = 64, blk_left = 0;  // current block, next pixel in it, blocks still owned
+    bool more = true;
+    const uint32_t nblocks = bxn * ((p.nrows + 7u) / 8u);
+    Popper pp;
+    pp.cq = home;
+    pp.cq_end = queue_lo(nblocks, home + 1u);
+
+    unsigned long long live_in = 0;
+    for (;;) {
+        // ---------------- retire lanes that escaped during this run ---------------------------------
+        const unsigned long long finished = live_in & ~live;
+        if ((finished >> lane) & 1ull) {
+            const int32_t count = cnt <= total ? (int32_t)cnt : 0;  // an escape past mrd-1 is "never"
+            if (p.counts) p.counts[opix] = count;
+            if (p.bytes) p.bytes[opix] = quantise(count, p.mrd, p.quant_wide);
+        }
+        live_in = live;
+        // ---------------- mrd deadline: lanes that ran mrd-1 steps without escaping -> 0 -------------
+        if ((int32_t)(n - bound) >= 0) {
+            const bool is_live = (live >> lane) & 1ull;
+            const uint32_t age = n - start;
+            const bool expired = is_live && age >= total;
+            if (expired) {
+                if (p.counts) p.counts[opix] = 0;
+                if (p.bytes) p.bytes[opix] = 0;
+            }
+            live &= ~__ballot(expired);
+            uint32_t rem = (is_live && !expired) ? total - age : kFar;
+            rem = wave_min_u32(rem < kFar ? rem : kFar);
+            bound = n + (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);  // uniform by construction
+        }
+        // ---------------- refill: free lanes take the next pixels of the wave's current block -----
+        const bool was_empty = (live == 0);
+        unsigned long long free_lanes = ~live;
+        while (more && free_lanes != 0) {
+            if (blk_pos >= 64u) {
+                if (blk_left > 0) {
+                    ++blk;
+                    --blk_left;
+                } else {
+                    uint32_t got;
+                    blk = pop_blocks(wq, pp, nblocks, home, lane, p.rf_batch, &got);
+                    if (blk == kNoBlock) {
+                        more = false;
+                        break;
+                    }
+                    blk_left = got - 1u;
+                }
+                blk_pos = 0;
+            }
+            const uint32_t navail = 64u - blk_pos;
+            const bool is_free = (free_lanes >> lane) & 1ull;
+            const uint32_t rank = (uint32_t)__popcll(free_lanes & ((1ull << lane) - 1ull));
+            const bool take = is_free && rank < navail;
+            bool valid = false;
+            if (take) {
+                const uint32_t pidx = blk_pos + rank;
+                const uint32_t by = blk / bxn, bx = blk - by * bxn;
+                const uint32_t lc = bx * 8u + (pidx & 7u), lr = by * 8u + (pidx >> 3);
+                if (lc < p.ncols && lr < p.nrows) {
+                    cr = axis_value(p.re, p.col0 + lc);
+                    ci = axis_value(p.im, p.row0 + lr);
+                    zr = cr;
+                    zi = ci;
+                    a = zr * zr;
+                    b = zi * zi;
+                    start = n;
+                    cnt = 0;
+                    opix = lr * p.ncols + lc;
+                    valid = true;
+                }
+            }
+            const unsigned long long taken = __ballot(take);
+            live |= __ballot(valid);
+            blk_pos += (uint32_t)__popcll(taken);
+            free_lanes = ~live;  // lanes whose pixel fell outside the window try again
+        }
+        if (live == 0) {
+            if (!more) break;
+            continue;  // every pixel taken this round was outside the window (ragged edge block)
+        }
+        if (was_empty) bound = n + (total < kFar ? total : kFar);
+
+        // ---------------- run ---------------------------------------------------------------------
+        live_in = live;
+        {
+            double t, pr, m;
+            uint32_t k, k2, k3;
+            unsigned long long save, tmp;
+            // all of these are wave-uniform by construction; say so to the register allocator
+            uint32_t alarm = uniform_u32(bound);
+            const uint32_t livemin = uniform_u32(more ? p.rf_livemin : 0u);     // refill once >= 16 lanes are free
+            const uint32_t patience = uniform_u32(more ? p.rf_patience : kFar);   // ... or 32 steps after an escape
+            n = uniform_u32(n);
+            live = uniform_u64(live);
+            if (kFmaDouble) {
+                asm volatile(MBK_RF_LOOP(MBK_STEP_HEAD_FMA)
+                             : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b),
+                               [cnt] "+&v"(cnt), [t] "=&v"(t), [p] "=&v"(pr), [m] "=&v"(m),
+                               [n] "+&s"(n), [live] "+&s"(live), [alarm] "+&s"(alarm),
+                               [k] "=&s"(k), [k2] "=&s"(k2), [k3] "=&s"(k3), [save] "=&s"(save),
+                               [tmp] "=&s"(tmp)
+                             : [cr] "v"(cr), [ci] "v"(ci), [start] "v"(start), [livemin] "s"(livemin),
+                               [patience] "s"(patience)
+                             : "vcc", "scc");
+            } else {
+                asm volatile(MBK_RF_LOOP(MBK_STEP_HEAD_SAFE)
+                             : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b),
+                               [cnt] "+&v"(cnt), [t] "=&v"(t), [p] "=&v"(pr), [m] "=&v"(m),
+                               [n] "+&s"(n), [live] "+&s"(live), [alarm] "+&s"(alarm),
+                               [k] "=&s"(k), [k2] "=&s"(k2), [k3] "=&s"(k3), [save] "=&s"(save),
+                               [tmp] "=&s"(tmp)
+                             : [cr] "v"(cr), [ci] "v"(ci), [start] "v"(start), [livemin] "s"(livemin),
+                               [patience] "s"(patience)
+                             : "vcc", "scc");
+            }
+        }
+
+    }
+}
+
+}  // namespace mbk

@@ -11,7 +11,7 @@ from distributedmandelbrot_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["default", "simple", "asm"]
+KERNELS = ["default", "simple", "asm", "refill"]
 
 
 def _check_view(gpu, oracle, view, mrd, window=None, kernel="default"):
