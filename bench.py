@@ -16,9 +16,11 @@ are count if count > 0 else mrd-1, summed from the kernel's own output (SURVEY.m
 `roofline`: the path is bound by the fp64 vector-ALU issue rate (not HBM, not MFMA -- FMA contraction
 is forbidden by bit-exactness): achieved = 8 algorithmic flops per pixel-iteration / average kernel
 launch duration (HIP events on the launch stream); peak = CUs x 4 SIMD x 16 fp64 lanes x 2 flop x
-clock (78.6 TFLOP/s on MI355X).  Under parity the stream is 7 fp64 VALU ops per 8 flops, so the
-flops fraction cannot exceed 8/14 = 0.571; `valu_slot_util` (= 7 issue slots per pixel-iteration
-over the 39.3 T lane-op/s issue peak) is the "how close to the metal" figure.
+clock (78.6 TFLOP/s on MI355X).  Under parity the default kernel needs 6.5 fp64-rate VALU issue
+slots per 8 flops (6 arithmetic ops per step + one add and one compare per 4 steps), so the flops
+fraction cannot exceed 8/13 = 0.615; `valu_slot_util` (= issue slots actually spent per
+pixel-iteration over the 39.3 T lane-op/s issue peak at 2.4 GHz) is the "how close to the metal"
+figure.
 `cpu_baseline`: the strict-IEEE C oracle (oracle/, kind "port": the reference has no CPU
 implementation and its numba path cannot run here) on the host cores, rank 0, N = 1 only.
 """
@@ -47,7 +49,9 @@ WORKLOADS = {
     "exterior": (-2.0, -2.0, 1.0, 4096, 4096, 1000, "DataChunk (4,0,0): every pixel escapes within 3 steps"),
 }
 FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
-VALU_OPS_PER_PIXEL_ITER = 7     # 3 mul + 3 add + 1 fma(2, p, ci)  (contraction-free stream)
+# fp64-rate VALU issue slots each kernel spends per pixel-iteration (v_cmp costs a full slot on gfx950):
+#   per-step test: 3 mul + 3 add + 1 fma + 1 v_cmp = 8;  grouped test (default): 6 + 2 per 4 steps = 6.5
+VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.5, "group": 6.5, "asm": 8.0, "simple": 8.0, "refill": 8.0}
 
 
 def parse_args():
@@ -202,6 +206,7 @@ def main():
         peak_lane_ops = cus * 4 * 16 * mhz * 1e6              # fp64 VALU lane-ops/s (16 lanes/clk/SIMD)
         peak_tflops = peak_lane_ops * 2 / 1e12                 # FMA = 2 flop -> 78.6 on MI355X
         achieved_tflops = FLOPS_PER_PIXEL_ITER * iters_per_step / avg_kernel_s / 1e12
+        slots = VALU_SLOTS_PER_PIXEL_ITER.get(args.kernel, 8.0)
         out_bytes = npix * 4
         rec = {
             "metric": "G pixel-iterations/s on 4096^2 tile, max_iter=1000 fp64",
@@ -232,8 +237,9 @@ def main():
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_ms_min": min(kernel_ms),
                 "flops_per_pixel_iteration": FLOPS_PER_PIXEL_ITER,
-                "parity_ceiling_frac": FLOPS_PER_PIXEL_ITER / (2.0 * VALU_OPS_PER_PIXEL_ITER),
-                "valu_slot_util": VALU_OPS_PER_PIXEL_ITER * iters_per_step / avg_kernel_s / peak_lane_ops,
+                "valu_slots_per_pixel_iteration": slots,
+                "parity_ceiling_frac": FLOPS_PER_PIXEL_ITER / (2.0 * slots),
+                "valu_slot_util": slots * iters_per_step / avg_kernel_s / peak_lane_ops,
                 "algorithmic_hbm_bytes_per_launch": out_bytes,
                 "hbm_GBps": out_bytes / avg_kernel_s / 1e9,
             },

@@ -21,8 +21,9 @@ MBK_KERNEL_DEFAULT = 0x000
 MBK_KERNEL_SIMPLE = 0x100
 MBK_KERNEL_ASM = 0x200
 MBK_KERNEL_REFILL = 0x300
+MBK_KERNEL_GROUP = 0x400
 KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MBK_KERNEL_ASM,
-           "refill": MBK_KERNEL_REFILL}
+           "refill": MBK_KERNEL_REFILL, "group": MBK_KERNEL_GROUP}
 MBK_CHUNK_DEFINITION = 4096
 MBK_CHUNK_BYTES = 4096 * 4096
 MBK_ABI_VERSION = 1

@@ -35,8 +35,10 @@ struct mbk_ctx {
     ReduceOut *d_red = nullptr;
     ReduceOut *h_red = nullptr;  // pinned
     WorkQueues *d_queues = nullptr;  // kQueueRing work-queue blocks for the persistent kernel
+    uint32_t *d_order = nullptr;     // kQueueRing dispatch-order lists (+2 cursors each)
+    size_t order_cap = 0;            // regions per list
     unsigned queue_turn = 0;
-    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 0, waves_per_wg = 1;  // tunables (MBK_* env)
+    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32;  // tunables (MBK_* env)
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -174,29 +176,50 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     a.rf_patience = ctx->rf_patience;
     a.rf_batch = ctx->rf_batch;
     a.perm_mul = 1u;
+    a.order = nullptr;
     a.counts = wc ? d_counts : nullptr;
     a.bytes = wb ? d_bytes : nullptr;
 
     const uint32_t kernel = flags & MBK_KERNEL_MASK;
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
+        case MBK_KERNEL_GROUP:
         case MBK_KERNEL_ASM: {
             const uint32_t wpw = ctx->waves_per_wg;  // 8x8-pixel blocks (= waves) per workgroup
             a.blocks_x = (v->ncols + 8u * wpw - 1u) / (8u * wpw);
             const uint32_t by = (v->nrows + 7u) / 8u;
             const dim3 grid(a.blocks_x * by), block(64u * wpw);
-            a.perm_mul = ctx->order ? coprime_multiplier(grid.x) : 1u;
+            a.perm_mul = ctx->order == 1 ? coprime_multiplier(grid.x) : 1u;
+            if (ctx->order == 2 && grid.x >= 4096u && mrd > 2u * ctx->probe_steps) {
+                // heavy-first dispatch order (see classify_blocks_kernel); tiny launches skip it
+                if (grid.x > ctx->order_cap) {
+                    if (ctx->d_order) (void)hipFree(ctx->d_order);
+                    ctx->d_order = nullptr;
+                    ctx->order_cap = 0;
+                    MBK_HIP(ctx, hipMalloc((void **)&ctx->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t) * kQueueRing));
+                    ctx->order_cap = grid.x;
+                }
+                uint32_t *ord = ctx->d_order + (ctx->order_cap + 2u) * (ctx->queue_turn++ % kQueueRing);
+                uint32_t *cursors = ord + ctx->order_cap;
+                MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 2 * sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0,
+                                   stream, a, grid.x, 8u * wpw, (int32_t)ctx->probe_steps, ord, cursors);
+                a.order = ord;
+            }
+            // dynamic LDS is never touched: it only caps how many workgroups a CU admits
             if (safe)
-                hipLaunchKernelGGL(mbk::tile_asm_kernel<false>, grid, block, 0, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<false, false>), grid, block, ctx->lds_pad, stream, a);
+            else if (kernel == MBK_KERNEL_ASM)
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, false>), grid, block, ctx->lds_pad, stream, a);
             else
-                hipLaunchKernelGGL(mbk::tile_asm_kernel<true>, grid, block, 0, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, true>), grid, block, ctx->lds_pad, stream, a);
             break;
         }
         case MBK_KERNEL_REFILL: {
             if (mrd < 2) {  // nothing to iterate: the plain kernel writes the zeros
                 a.blocks_x = (v->ncols + 31u) / 32u;
                 const dim3 grid(a.blocks_x * ((v->nrows + 7u) / 8u)), block(256);
-                hipLaunchKernelGGL(mbk::tile_asm_kernel<true>, grid, block, 0, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, false>), grid, block, 0, stream, a);
                 break;
             }
             const uint32_t nblocks = ((v->ncols + 7u) / 8u) * ((v->nrows + 7u) / 8u);
@@ -301,6 +324,8 @@ int mbk_create(int device, mbk_ctx **out)
     if (const char *e = std::getenv("MBK_RF_LIVEMIN")) ctx->rf_livemin = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_RF_PATIENCE")) ctx->rf_patience = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_WPW")) { unsigned w = (unsigned)std::atoi(e); if (w == 1 || w == 2 || w == 4) ctx->waves_per_wg = w; }
+    if (const char *e = std::getenv("MBK_PROBE")) ctx->probe_steps = (unsigned)std::atoi(e) > 1 ? (unsigned)std::atoi(e) : 2u;
+    if (const char *e = std::getenv("MBK_LDS")) ctx->lds_pad = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_ORDER")) ctx->order = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_RF_BATCH")) ctx->rf_batch = (unsigned)std::atoi(e) > 0 ? (unsigned)std::atoi(e) : 1u;
     if (const char *e = std::getenv("MBK_RF_WAVES")) ctx->rf_waves_per_simd = (unsigned)std::atoi(e);
@@ -343,6 +368,7 @@ void mbk_destroy(mbk_ctx *ctx)
     if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
     if (ctx->d_red) (void)hipFree(ctx->d_red);
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);

@@ -45,6 +45,7 @@ struct TileArgs {
     uint32_t rf_patience; // ... or this many steps after the first unrefilled escape
     uint32_t rf_batch;    // 8x8 blocks taken per queue pop
     uint32_t perm_mul;    // workgroup order: block = (blockIdx * perm_mul) mod gridDim (1 = row-major)
+    const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel)
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
 };
@@ -224,7 +225,110 @@ __device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_
     return cnt;
 }
 
-template <bool kFmaDouble>
+// ---------------------------------------------------------------------------------------------
+// Grouped bailout test ("group" loop).  The bailout compare costs a full fp64 issue slot (v_cmp writes
+// an SGPR pair: 4.4 cycles, measured) and needs m = a + b, another slot: 2 of the 8 slots of a step.
+// Once |z|^2 >= 4 the orbit cannot come back below 4 (for |c| <= 2 - 1e-9:
+// |z'| >= |z|^2 - |c| >= 2 with margin over rounding; for |c| >= 2 + 1e-9 it escapes at step 1 and
+// |z| >= |c| grows; it ends in inf and then NaN), so it is enough to test after every G = 4 steps
+// with a NaN-inclusive compare (v_cmp_ngt_f64 vcc, 4.0, m == !(4 > m)), and to find the exact step
+// afterwards: the four unchecked steps run on a scratch register set and leave the group's start
+// state intact, so the lanes that tripped the test REPLAY those four steps with the exact per-step
+// IEEE test (v_cmp_le_f64 4.0 <= m) and record the first hit.  Result: 6 fp64 VALU per step + 2 per
+// group = 6.5 slots per step instead of 8, bit-identical counts.
+// Waves that contain a pixel with | |c|^2 - 4 | < 1e-9 (the one place where "stays >= 4" could be
+// spoiled by rounding) take the per-step loop instead (tile_asm_kernel's `risky` branch).
+// Register sets: A = (zr, zi, a, b) and B = (zr2, zi2, a2, b2) alternate as group start/end; T is the
+// scratch set.  One loop trip = group A->B + group B->A = 8 steps.
+// ---------------------------------------------------------------------------------------------
+#define MBK_G_STEP(ZRS, ZIS, AS, BS, ZRD, ZID, AD, BD)     \
+    "v_add_f64 %[t], " AS ", -" BS "\n"                    \
+    "v_mul_f64 %[p], " ZRS ", " ZIS "\n"                   \
+    "v_add_f64 " ZRD ", %[t], %[cr]\n"                     \
+    "v_fma_f64 " ZID ", %[p], 2.0, %[ci]\n"                \
+    "v_mul_f64 " AD ", " ZRD ", " ZRD "\n"                 \
+    "v_mul_f64 " BD ", " ZID ", " ZID "\n"
+#define MBK_G_A2T MBK_G_STEP("%[zr]", "%[zi]", "%[a]", "%[b]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
+#define MBK_G_B2T MBK_G_STEP("%[zr2]", "%[zi2]", "%[a2]", "%[b2]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
+#define MBK_G_T2T MBK_G_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
+#define MBK_G_T2A MBK_G_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zr]", "%[zi]", "%[a]", "%[b]")
+#define MBK_G_T2B MBK_G_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zr2]", "%[zi2]", "%[a2]", "%[b2]")
+// four unchecked steps (FIRST, T2T, T2T, LAST), then the NaN-inclusive group test on the end set
+#define MBK_G_GROUP(FIRST, LAST, AD, BD, ID)               \
+    FIRST MBK_G_T2T MBK_G_T2T LAST                         \
+    "v_add_f64 %[m], " AD ", " BD "\n"                     \
+    "v_cmp_ngt_f64 vcc, 4.0, %[m]\n"                       \
+    "s_cbranch_vccnz .Lgrep" ID "_%=\n"                    \
+    ".Lgcont" ID "_%=:\n"
+// one replayed step (STEP writes set T) with the exact test; hits record clock n+J and leave EXEC
+#define MBK_G_REPLAY_STEP(STEP, J)                         \
+    STEP                                                   \
+    "v_add_f64 %[m], %[at], %[bt]\n"                       \
+    "v_cmp_le_f64 vcc, 4.0, %[m]\n"                        \
+    "s_add_u32 %[k], %[n], " J "\n"                        \
+    "s_or_b64 %[esc], %[esc], vcc\n"                       \
+    "s_and_saveexec_b64 %[tmp2], vcc\n"                    \
+    "v_mov_b32 %[cnt], %[k]\n"                             \
+    "s_andn2_b64 exec, %[tmp2], vcc\n"
+// replay of a whole group from its intact start set
+#define MBK_G_REPLAY(FIRST, ID, J1, J2, J3, J4)            \
+    ".Lgrep" ID "_%=:\n"                                   \
+    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
+    "s_mov_b64 %[esc], 0\n"                                \
+    MBK_G_REPLAY_STEP(FIRST, J1) MBK_G_REPLAY_STEP(MBK_G_T2T, J2) \
+    MBK_G_REPLAY_STEP(MBK_G_T2T, J3) MBK_G_REPLAY_STEP(MBK_G_T2T, J4) \
+    "s_andn2_b64 exec, %[tmp], %[esc]\n"                   \
+    "s_cbranch_scc1 .Lgcont" ID "_%=\n"                    \
+    "s_branch .Lgdone_%=\n"
+#define MBK_G_LOOP                                         \
+    "s_mov_b64 %[save], exec\n"                            \
+    "s_mov_b32 %[n], 0\n"                                  \
+    "s_cmp_eq_u32 %[limit8], 0\n"                          \
+    "s_cbranch_scc1 .Lgtail_%=\n"                          \
+    ".Lgmain_%=:\n"                                        \
+    MBK_G_GROUP(MBK_G_A2T, MBK_G_T2B, "%[a2]", "%[b2]", "1") \
+    MBK_G_GROUP(MBK_G_B2T, MBK_G_T2A, "%[a]", "%[b]", "2")    \
+    "s_add_u32 %[n], %[n], 8\n"                            \
+    "s_cmp_lt_u32 %[n], %[limit8]\n"                       \
+    "s_cbranch_scc1 .Lgmain_%=\n"                          \
+    ".Lgtail_%=:\n"                                        \
+    "s_cmp_ge_u32 %[n], %[total]\n"                        \
+    "s_cbranch_scc1 .Lgdone_%=\n"                          \
+    ".Lgtloop_%=:\n"                                       \
+    MBK_STEP_HEAD_FMA MBK_STEP_TAIL("GT")                  \
+    "s_add_u32 %[n], %[n], 1\n"                            \
+    "s_cmp_lt_u32 %[n], %[total]\n"                        \
+    "s_cbranch_scc1 .Lgtloop_%=\n"                         \
+    "s_branch .Lgdone_%=\n"                                \
+    MBK_G_REPLAY(MBK_G_A2T, "1", "1", "2", "3", "4")       \
+    MBK_G_REPLAY(MBK_G_B2T, "2", "5", "6", "7", "8")       \
+    MBK_ESCAPE("GT", "1")                                  \
+    ".Ldone_%=:\n"                                         \
+    ".Lgdone_%=:\n"                                        \
+    "s_mov_b64 exec, %[save]\n"
+
+__device__ __forceinline__ int32_t escape_count_group(double cr, double ci, int32_t mrd)
+{
+    double zr = cr, zi = ci;
+    double a = zr * zr, b = zi * zi;
+    double zr2, zi2, a2, b2, zrt, zit, at, bt, t, p, m;
+    int32_t cnt = 0;
+    const uint32_t total = mrd > 1 ? (uint32_t)mrd - 1u : 0u;
+    const uint32_t limit8 = total & ~7u;
+    uint32_t n, k;
+    unsigned long long save, tmp, tmp2, esc;
+    asm volatile(MBK_G_LOOP
+                 : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
+                   [zr2] "=&v"(zr2), [zi2] "=&v"(zi2), [a2] "=&v"(a2), [b2] "=&v"(b2),
+                   [zrt] "=&v"(zrt), [zit] "=&v"(zit), [at] "=&v"(at), [bt] "=&v"(bt),
+                   [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
+                   [save] "=&s"(save), [tmp] "=&s"(tmp), [tmp2] "=&s"(tmp2), [esc] "=&s"(esc)
+                 : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit8] "s"(limit8)
+                 : "vcc", "scc");
+    return cnt;
+}
+
+template <bool kFmaDouble, bool kGrouped = false>
 __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -232,17 +336,85 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     // Dispatch order != image order: consecutive workgroup ids are scattered over the tile by a
     // multiplicative permutation (perm_mul coprime to the grid size), so the long-running in-set
     // blocks do not arrive in clusters.
-    const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
+    const uint32_t blk = p.order ? p.order[blockIdx.x]
+                                 : (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
     const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
     const uint32_t lc = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);  // one 8x8 block per wave
     const uint32_t lr = by * 8u + (lane >> 3);
     if (lc >= p.ncols || lr >= p.nrows) return;
     const double cr = axis_value(p.re, p.col0 + lc);
     const double ci = axis_value(p.im, p.row0 + lr);
-    const int32_t count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd);
+    int32_t count;
+    if (kGrouped && kFmaDouble) {
+        // the grouped test relies on "|z|^2 >= 4 stays >= 4"; only |c| within rounding of 2 could
+        // spoil that, so any wave touching that ring takes the per-step loop (wave-uniform branch)
+        const double c2 = cr * cr + ci * ci;
+        const bool risky = __any(c2 > 4.0 - 1e-9 && c2 < 4.0 + 1e-9) != 0;
+        count = risky ? escape_count_asm<true>(cr, ci, p.mrd) : escape_count_group(cr, ci, p.mrd);
+    } else {
+        count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd);
+    }
     const size_t o = (size_t)lr * p.ncols + lc;
     if (p.counts) p.counts[o] = count;
     if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dispatch-order pre-pass ("heavy first").  Why: the hardware hands workgroups out in index order.
+// In image order, cheap blocks (every pixel escapes within a few steps: 83 % of cfg2) are interleaved
+// with in-set blocks; each time a long-running wave retires, its slot hosts a string of cheap waves
+// (~10 us each, almost no VALU work) before the next long one arrives, so the SIMDs run with ~5
+// useful waves instead of 8, and the tile ends with a drain of long waves and nothing to overlap it.
+// Measured on cfg2 (profiles/microbench/occupancy_trace.hip): heavy-first order -10 % kernel time.
+// This kernel probes ONE pixel per workgroup region (its centre) for `probe_steps` steps and
+// builds the order: regions whose probe did not escape go to the front of `order` (atomic cursor
+// counters[0]), the others are filled in from the back (counters[1]).  It is a scheduling heuristic
+// only: a mis-classified block is merely computed earlier or later; results cannot change.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void classify_blocks_kernel(TileArgs p, uint32_t nregions,
+                                                                uint32_t region_w, int32_t probe_steps,
+                                                                uint32_t *order, uint32_t *counters)
+{
+    __shared__ uint32_t s_heavy[16], s_light[16], s_base[2];
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    bool valid = r < nregions, heavy = false;
+    if (valid) {
+        const uint32_t by = r / p.blocks_x, bx = r - by * p.blocks_x;
+        uint32_t lc = bx * region_w + region_w / 2u, lr = by * 8u + 4u;
+        lc = lc < p.ncols ? lc : p.ncols - 1u;
+        lr = lr < p.nrows ? lr : p.nrows - 1u;
+        const double cr = axis_value(p.re, p.col0 + lc), ci = axis_value(p.im, p.row0 + lr);
+        const int32_t cap = p.mrd < probe_steps ? p.mrd : probe_steps;
+        heavy = cap > 1 && escape_count<true>(cr, ci, cap) == 0;
+    }
+    const unsigned long long hm = __ballot(valid && heavy), lm = __ballot(valid && !heavy);
+    if (lane == 0) {
+        s_heavy[wave] = (uint32_t)__popcll(hm);
+        s_light[wave] = (uint32_t)__popcll(lm);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t h = 0, l = 0;
+        const uint32_t nw = (blockDim.x + 63u) >> 6;
+        for (uint32_t w = 0; w < nw; ++w) {
+            const uint32_t hw = s_heavy[w], lw = s_light[w];
+            s_heavy[w] = h;
+            s_light[w] = l;
+            h += hw;
+            l += lw;
+        }
+        s_base[0] = h ? atomicAdd(&counters[0], h) : 0u;
+        s_base[1] = l ? atomicAdd(&counters[1], l) : 0u;
+    }
+    __syncthreads();
+    if (valid) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (heavy)
+            order[s_base[0] + s_heavy[wave] + (uint32_t)__popcll(hm & below)] = r;
+        else
+            order[nregions - 1u - (s_base[1] + s_light[wave] + (uint32_t)__popcll(lm & below))] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ from distributedmandelbrot_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["default", "simple", "asm", "refill"]
+KERNELS = ["default", "simple", "asm", "refill", "group"]
 
 
 def _check_view(gpu, oracle, view, mrd, window=None, kernel="default"):
