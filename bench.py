@@ -16,9 +16,9 @@ are count if count > 0 else mrd-1, summed from the kernel's own output (SURVEY.m
 `roofline`: the path is bound by the fp64 vector-ALU issue rate (not HBM, not MFMA -- FMA contraction
 is forbidden by bit-exactness): achieved = 8 algorithmic flops per pixel-iteration / average kernel
 launch duration (HIP events on the launch stream); peak = CUs x 4 SIMD x 16 fp64 lanes x 2 flop x
-clock (78.6 TFLOP/s on MI355X).  Under parity the default kernel needs 6.5 fp64-rate VALU issue
-slots per 8 flops (6 arithmetic ops per step + one add and one compare per 4 steps), so the flops
-fraction cannot exceed 8/13 = 0.615; `valu_slot_util` (= issue slots actually spent per
+clock (78.6 TFLOP/s on MI355X).  Under parity the default kernel needs 6.25 fp64-rate VALU issue
+slots per 8 flops (6 arithmetic ops per step + one add and one compare per 8 steps), so the flops
+fraction cannot exceed 8/12.5 = 0.64; `valu_slot_util` (= issue slots actually spent per
 pixel-iteration over the 39.3 T lane-op/s issue peak at 2.4 GHz) is the "how close to the metal"
 figure.
 `cpu_baseline`: the strict-IEEE C oracle (oracle/, kind "port": the reference has no CPU
@@ -50,8 +50,8 @@ WORKLOADS = {
 }
 FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
 # fp64-rate VALU issue slots each kernel spends per pixel-iteration (v_cmp costs a full slot on gfx950):
-#   per-step test: 3 mul + 3 add + 1 fma + 1 v_cmp = 8;  grouped test (default): 6 + 2 per 4 steps = 6.5
-VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.5, "group": 6.5, "asm": 8.0, "simple": 8.0, "refill": 8.0}
+#   per-step test: 3 mul + 3 add + 1 fma + 1 v_cmp = 8;  grouped test (default): 6 + 2 per 8 steps = 6.25
+VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.25, "group": 6.25, "asm": 8.0, "simple": 8.0, "refill": 8.0}
 
 
 def parse_args():

@@ -38,7 +38,7 @@ struct mbk_ctx {
     uint32_t *d_order = nullptr;     // kQueueRing dispatch-order lists (+2 cursors each)
     size_t order_cap = 0;            // regions per list
     unsigned queue_turn = 0;
-    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32;  // tunables (MBK_* env)
+    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32, group_steps = 8;  // tunables (MBK_* env)
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -208,18 +208,20 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
             }
             // dynamic LDS is never touched: it only caps how many workgroups a CU admits
             if (safe)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<false, false>), grid, block, ctx->lds_pad, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<false, 0>), grid, block, ctx->lds_pad, stream, a);
             else if (kernel == MBK_KERNEL_ASM)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, false>), grid, block, ctx->lds_pad, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 0>), grid, block, ctx->lds_pad, stream, a);
+            else if (ctx->group_steps == 8)
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 8>), grid, block, ctx->lds_pad, stream, a);
             else
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, true>), grid, block, ctx->lds_pad, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 4>), grid, block, ctx->lds_pad, stream, a);
             break;
         }
         case MBK_KERNEL_REFILL: {
             if (mrd < 2) {  // nothing to iterate: the plain kernel writes the zeros
                 a.blocks_x = (v->ncols + 31u) / 32u;
                 const dim3 grid(a.blocks_x * ((v->nrows + 7u) / 8u)), block(256);
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, false>), grid, block, 0, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 0>), grid, block, 0, stream, a);
                 break;
             }
             const uint32_t nblocks = ((v->ncols + 7u) / 8u) * ((v->nrows + 7u) / 8u);
@@ -324,6 +326,7 @@ int mbk_create(int device, mbk_ctx **out)
     if (const char *e = std::getenv("MBK_RF_LIVEMIN")) ctx->rf_livemin = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_RF_PATIENCE")) ctx->rf_patience = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_WPW")) { unsigned w = (unsigned)std::atoi(e); if (w == 1 || w == 2 || w == 4) ctx->waves_per_wg = w; }
+    if (const char *e = std::getenv("MBK_GROUP")) ctx->group_steps = (unsigned)std::atoi(e) == 4 ? 4u : 8u;
     if (const char *e = std::getenv("MBK_PROBE")) ctx->probe_steps = (unsigned)std::atoi(e) > 1 ? (unsigned)std::atoi(e) : 2u;
     if (const char *e = std::getenv("MBK_LDS")) ctx->lds_pad = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_ORDER")) ctx->order = (unsigned)std::atoi(e);

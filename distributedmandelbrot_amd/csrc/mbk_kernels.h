@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
     "s_branch .Ldone_%=\n"
 #define MBK_LOOP_ASM(HEAD)                                 \
     "s_mov_b64 %[save], exec\n"                            \
-    "s_mov_b32 %[n], 0\n"                                  \
-    "s_cmp_eq_u32 %[limit4], 0\n"                          \
+    "s_mov_b32 %[n], %[n0]\n"                              \
+    "s_cmp_ge_u32 %[n], %[limit4]\n"                       \
     "s_cbranch_scc1 .Ltail_%=\n"                           \
     ".Lmain_%=:\n"                                         \
     HEAD MBK_STEP_TAIL("1") HEAD MBK_STEP_TAIL("2")        \
@@ -196,15 +196,15 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
     ".Ldone_%=:\n"                                         \
     "s_mov_b64 exec, %[save]\n"
 
+// Per-step loop: runs steps n0+1 .. stop on the state (zr, zi, a = zr^2, b = zi^2); lanes that escape
+// get cnt = step index and leave; survivors keep cnt unchanged and their state advanced to `stop`.
 template <bool kFmaDouble>
-__device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_t mrd)
+__device__ __forceinline__ void escape_steps_asm(double cr, double ci, double &zr, double &zi, double &a,
+                                                 double &b, int32_t &cnt, uint32_t n0, uint32_t stop)
 {
-    double zr = cr, zi = ci;
-    double a = zr * zr, b = zi * zi;
     double t, p, m;
-    int32_t cnt = 0;
-    const uint32_t total = mrd > 1 ? (uint32_t)mrd - 1u : 0u;  // number of z updates (uniform)
-    const uint32_t limit4 = total & ~3u;
+    const uint32_t total = stop;                         // uniform
+    const uint32_t limit4 = n0 + ((stop - n0) & ~3u);    // whole 4-step trips
     uint32_t n, k;
     unsigned long long save, tmp;
     if (kFmaDouble) {
@@ -212,16 +212,25 @@ __device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_
                      : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
                        [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
                        [save] "=&s"(save), [tmp] "=&s"(tmp)
-                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4)
+                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4), [n0] "s"(n0)
                      : "vcc", "scc");
     } else {
         asm volatile(MBK_LOOP_ASM(MBK_STEP_HEAD_SAFE)
                      : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
                        [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
                        [save] "=&s"(save), [tmp] "=&s"(tmp)
-                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4)
+                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4), [n0] "s"(n0)
                      : "vcc", "scc");
     }
+}
+
+template <bool kFmaDouble>
+__device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_t mrd)
+{
+    double zr = cr, zi = ci;
+    double a = zr * zr, b = zi * zi;
+    int32_t cnt = 0;
+    escape_steps_asm<kFmaDouble>(cr, ci, zr, zi, a, b, cnt, 0u, mrd > 1 ? (uint32_t)mrd - 1u : 0u);
     return cnt;
 }
 
@@ -282,8 +291,8 @@ __device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_
     "s_branch .Lgdone_%=\n"
 #define MBK_G_LOOP                                         \
     "s_mov_b64 %[save], exec\n"                            \
-    "s_mov_b32 %[n], 0\n"                                  \
-    "s_cmp_eq_u32 %[limit8], 0\n"                          \
+    "s_mov_b32 %[n], %[n0]\n"                              \
+    "s_cmp_ge_u32 %[n], %[limit8]\n"                          \
     "s_cbranch_scc1 .Lgtail_%=\n"                          \
     ".Lgmain_%=:\n"                                        \
     MBK_G_GROUP(MBK_G_A2T, MBK_G_T2B, "%[a2]", "%[b2]", "1") \
@@ -307,28 +316,93 @@ __device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_
     ".Lgdone_%=:\n"                                        \
     "s_mov_b64 exec, %[save]\n"
 
-__device__ __forceinline__ int32_t escape_count_group(double cr, double ci, int32_t mrd)
+// ---- same scheme with 8 steps per group (6.25 slots per step; one trip = 16 steps) -------------
+#define MBK_G_GROUP8(FIRST, LAST, AD, BD, ID)              \
+    FIRST MBK_G_T2T MBK_G_T2T MBK_G_T2T MBK_G_T2T MBK_G_T2T MBK_G_T2T LAST \
+    "v_add_f64 %[m], " AD ", " BD "\n"                     \
+    "v_cmp_ngt_f64 vcc, 4.0, %[m]\n"                       \
+    "s_cbranch_vccnz .Lgrep" ID "_%=\n"                    \
+    ".Lgcont" ID "_%=:\n"
+#define MBK_G_REPLAY8(FIRST, ID, J1, J2, J3, J4, J5, J6, J7, J8) \
+    ".Lgrep" ID "_%=:\n"                                   \
+    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
+    "s_mov_b64 %[esc], 0\n"                                \
+    MBK_G_REPLAY_STEP(FIRST, J1) MBK_G_REPLAY_STEP(MBK_G_T2T, J2) \
+    MBK_G_REPLAY_STEP(MBK_G_T2T, J3) MBK_G_REPLAY_STEP(MBK_G_T2T, J4) \
+    MBK_G_REPLAY_STEP(MBK_G_T2T, J5) MBK_G_REPLAY_STEP(MBK_G_T2T, J6) \
+    MBK_G_REPLAY_STEP(MBK_G_T2T, J7) MBK_G_REPLAY_STEP(MBK_G_T2T, J8) \
+    "s_andn2_b64 exec, %[tmp], %[esc]\n"                   \
+    "s_cbranch_scc1 .Lgcont" ID "_%=\n"                    \
+    "s_branch .Lgdone_%=\n"
+#define MBK_G_LOOP8                                        \
+    "s_mov_b64 %[save], exec\n"                            \
+    "s_mov_b32 %[n], %[n0]\n"                              \
+    "s_cmp_ge_u32 %[n], %[limit8]\n"                          \
+    "s_cbranch_scc1 .Lgtail_%=\n"                          \
+    ".Lgmain_%=:\n"                                        \
+    MBK_G_GROUP8(MBK_G_A2T, MBK_G_T2B, "%[a2]", "%[b2]", "1") \
+    MBK_G_GROUP8(MBK_G_B2T, MBK_G_T2A, "%[a]", "%[b]", "2")   \
+    "s_add_u32 %[n], %[n], 16\n"                           \
+    "s_cmp_lt_u32 %[n], %[limit8]\n"                       \
+    "s_cbranch_scc1 .Lgmain_%=\n"                          \
+    ".Lgtail_%=:\n"                                        \
+    "s_cmp_ge_u32 %[n], %[total]\n"                        \
+    "s_cbranch_scc1 .Lgdone_%=\n"                          \
+    ".Lgtloop_%=:\n"                                       \
+    MBK_STEP_HEAD_FMA MBK_STEP_TAIL("GT")                  \
+    "s_add_u32 %[n], %[n], 1\n"                            \
+    "s_cmp_lt_u32 %[n], %[total]\n"                        \
+    "s_cbranch_scc1 .Lgtloop_%=\n"                         \
+    "s_branch .Lgdone_%=\n"                                \
+    MBK_G_REPLAY8(MBK_G_A2T, "1", "1", "2", "3", "4", "5", "6", "7", "8")       \
+    MBK_G_REPLAY8(MBK_G_B2T, "2", "9", "10", "11", "12", "13", "14", "15", "16") \
+    MBK_ESCAPE("GT", "1")                                  \
+    ".Ldone_%=:\n"                                         \
+    ".Lgdone_%=:\n"                                        \
+    "s_mov_b64 exec, %[save]\n"
+
+// Grouped loop on an existing state: steps n0+1 .. total (see escape_steps_asm for the contract).
+template <int kGroup = 4>
+__device__ __forceinline__ void escape_steps_group(double cr, double ci, double &zr, double &zi, double &a,
+                                                   double &b, int32_t &cnt, uint32_t n0, uint32_t total)
 {
-    double zr = cr, zi = ci;
-    double a = zr * zr, b = zi * zi;
     double zr2, zi2, a2, b2, zrt, zit, at, bt, t, p, m;
-    int32_t cnt = 0;
-    const uint32_t total = mrd > 1 ? (uint32_t)mrd - 1u : 0u;
-    const uint32_t limit8 = total & ~7u;
+    const uint32_t limit8 = n0 + ((total - n0) & (kGroup == 8 ? ~15u : ~7u));  // whole trips only
     uint32_t n, k;
     unsigned long long save, tmp, tmp2, esc;
-    asm volatile(MBK_G_LOOP
-                 : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
-                   [zr2] "=&v"(zr2), [zi2] "=&v"(zi2), [a2] "=&v"(a2), [b2] "=&v"(b2),
-                   [zrt] "=&v"(zrt), [zit] "=&v"(zit), [at] "=&v"(at), [bt] "=&v"(bt),
-                   [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
-                   [save] "=&s"(save), [tmp] "=&s"(tmp), [tmp2] "=&s"(tmp2), [esc] "=&s"(esc)
-                 : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit8] "s"(limit8)
-                 : "vcc", "scc");
+#define MBK_G_OPERANDS                                                                          \
+                 : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),  \
+                   [zr2] "=&v"(zr2), [zi2] "=&v"(zi2), [a2] "=&v"(a2), [b2] "=&v"(b2),            \
+                   [zrt] "=&v"(zrt), [zit] "=&v"(zit), [at] "=&v"(at), [bt] "=&v"(bt),            \
+                   [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),          \
+                   [save] "=&s"(save), [tmp] "=&s"(tmp), [tmp2] "=&s"(tmp2), [esc] "=&s"(esc)     \
+                 : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit8] "s"(limit8), [n0] "s"(n0) \
+                 : "vcc", "scc"
+    if (kGroup == 8) {
+        asm volatile(MBK_G_LOOP8 MBK_G_OPERANDS);
+    } else {
+        asm volatile(MBK_G_LOOP MBK_G_OPERANDS);
+    }
+#undef MBK_G_OPERANDS
+}
+
+// Default pixel routine: the first kExactSteps steps with the per-step test (most escaping pixels leave
+// here and never pay a group + replay), the rest in groups.
+template <int kGroup = 4>
+__device__ __forceinline__ int32_t escape_count_group(double cr, double ci, int32_t mrd)
+{
+    constexpr uint32_t kExactSteps = 8;
+    double zr = cr, zi = ci;
+    double a = zr * zr, b = zi * zi;
+    int32_t cnt = 0;
+    const uint32_t total = mrd > 1 ? (uint32_t)mrd - 1u : 0u;
+    const uint32_t first = total < kExactSteps ? total : kExactSteps;
+    escape_steps_asm<true>(cr, ci, zr, zi, a, b, cnt, 0u, first);
+    if (cnt == 0 && total > first) escape_steps_group<kGroup>(cr, ci, zr, zi, a, b, cnt, first, total);
     return cnt;
 }
 
-template <bool kFmaDouble, bool kGrouped = false>
+template <bool kFmaDouble, int kGroup = 0>
 __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -345,12 +419,13 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     const double cr = axis_value(p.re, p.col0 + lc);
     const double ci = axis_value(p.im, p.row0 + lr);
     int32_t count;
-    if (kGrouped && kFmaDouble) {
+    if (kGroup != 0 && kFmaDouble) {
         // the grouped test relies on "|z|^2 >= 4 stays >= 4"; only |c| within rounding of 2 could
         // spoil that, so any wave touching that ring takes the per-step loop (wave-uniform branch)
         const double c2 = cr * cr + ci * ci;
         const bool risky = __any(c2 > 4.0 - 1e-9 && c2 < 4.0 + 1e-9) != 0;
-        count = risky ? escape_count_asm<true>(cr, ci, p.mrd) : escape_count_group(cr, ci, p.mrd);
+        count = risky ? escape_count_asm<true>(cr, ci, p.mrd)
+                      : escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd);
     } else {
         count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd);
     }
