@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="tiles in flight per GPU: steps are issued round-robin on this many HIP streams "
+                         "(1 = the contract's serial steps; 2 lets the next tile fill the drain of the last)")
     return ap.parse_args()
 
 
@@ -150,12 +153,19 @@ def main():
         dev = MandelbrotDevice(local_rank)   # raises loudly without the HIP library / a gfx950 GPU
         device_info = dev.info()
         view = View(sr, si, rng, rng, width, height)
-        d_counts = torch.empty(npix, dtype=torch.int32, device=f"cuda:{local_rank}")
-        stream = torch.cuda.current_stream()
+        nstreams = max(1, args.streams)
+        d_counts_all = [torch.empty(npix, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(nstreams)]
+        d_counts = d_counts_all[0]
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
+        stream = streams[0]
+        turn = [0]
 
         def launch():
-            dev.launch_view(view, mrd, d_counts=d_counts.data_ptr(), stream=stream.cuda_stream,
+            i = turn[0] % nstreams
+            turn[0] += 1
+            dev.launch_view(view, mrd, d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
                             kernel=args.kernel)
+            return streams[i]
 
         def sync():
             torch.cuda.synchronize()
@@ -169,9 +179,10 @@ def main():
     for _ in range(args.steps):
         if not fake:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
+            st_ = streams[turn[0] % nstreams]
+            e0.record(st_)
             launch()
-            e1.record(stream)
+            e1.record(st_)
             events.append((e0, e1))
         else:
             launch()
@@ -225,6 +236,7 @@ def main():
                                    "written to resident HBM", "kernel": args.kernel,
                        "pixels_per_step_per_gpu": npix, "pixel_iterations_per_step_per_gpu": iters_per_step,
                        "never_escaped_pixels": never, "parallelism": f"{world} independent tile queue(s), no collective",
+                       "streams_per_gpu": max(1, args.streams),
                        "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus,
                        "clock_mhz": mhz},
             "roofline": {

@@ -24,6 +24,8 @@ MBK_KERNEL_REFILL = 0x300
 MBK_KERNEL_GROUP = 0x400
 KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MBK_KERNEL_ASM,
            "refill": MBK_KERNEL_REFILL, "group": MBK_KERNEL_GROUP}
+MBK_CODEC_RAW = 0x00
+MBK_CODEC_RLE = 0x01
 MBK_CHUNK_DEFINITION = 4096
 MBK_CHUNK_BYTES = 4096 * 4096
 MBK_ABI_VERSION = 1
@@ -40,7 +42,8 @@ class mbk_view(C.Structure):
 class mbk_stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_float), ("d2h_ms", C.c_float),
                 ("pixel_iterations", C.c_uint64), ("never_pixels", C.c_uint64),
-                ("all_bytes_zero", C.c_uint32), ("all_bytes_one", C.c_uint32)]
+                ("all_bytes_zero", C.c_uint32), ("all_bytes_one", C.c_uint32),
+                ("rle_runs", C.c_uint64)]
 
 
 class mbk_device_info(C.Structure):
@@ -68,6 +71,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.POINTER(mbk_stats)]),
     "mbk_datachunk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.POINTER(mbk_stats)]),
+    "mbk_serialize_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint32)]),
     "mbk_reduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                     C.POINTER(mbk_stats)]),
 }

@@ -37,6 +37,9 @@ struct mbk_ctx {
     WorkQueues *d_queues = nullptr;  // kQueueRing work-queue blocks for the persistent kernel
     uint32_t *d_order = nullptr;     // kQueueRing dispatch-order lists (+2 cursors each)
     size_t order_cap = 0;            // regions per list
+    size_t last_px = 0;              // pixels of the last tile computed with bytes (for mbk_serialize_last)
+    uint8_t *d_rle = nullptr;        // RLE scratch: block counts | run starts | run values | output stream
+    size_t rle_cap_px = 0;
     unsigned queue_turn = 0;
     unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32, group_steps = 8;  // tunables (MBK_* env)
     hipDeviceProp_t prop;
@@ -194,6 +197,7 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
                 // heavy-first dispatch order (see classify_blocks_kernel); tiny launches skip it
                 if (grid.x > ctx->order_cap) {
                     if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->d_rle) (void)hipFree(ctx->d_rle);
                     ctx->d_order = nullptr;
                     ctx->order_cap = 0;
                     MBK_HIP(ctx, hipMalloc((void **)&ctx->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t) * kQueueRing));
@@ -288,6 +292,7 @@ static void fill_stats_from_reduce(const mbk_ctx *ctx, mbk_stats *s, bool have_b
     s->never_pixels = ctx->h_red->never_pixels;
     s->all_bytes_zero = have_bytes && ctx->h_red->any_byte_not_zero == 0 ? 1u : 0u;
     s->all_bytes_one = have_bytes && ctx->h_red->any_byte_not_one == 0 ? 1u : 0u;
+    s->rle_runs = have_bytes ? ctx->h_red->run_starts : 0ull;
 }
 
 // ------------------------------------- C ABI ---------------------------------------------------
@@ -372,6 +377,7 @@ void mbk_destroy(mbk_ctx *ctx)
     if (ctx->d_red) (void)hipFree(ctx->d_red);
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->d_rle) (void)hipFree(ctx->d_rle);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
@@ -468,6 +474,7 @@ int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t 
                                     ctx->stream));
     MBK_HIP(ctx, hipEventRecord(ctx->ev_c1, ctx->stream));
     MBK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_px = wb ? px : 0;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev_k0, ctx->ev_k1));
@@ -498,6 +505,59 @@ int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_rea
     v.ncols = v.nrows = MBK_CHUNK_DEFINITION;
     const uint32_t flags = MBK_WANT_BYTES | (h_counts ? MBK_WANT_COUNTS : 0u);
     return mbk_view_compute(ctx, &v, mrd, flags, h_counts, h_bytes, stats);
+}
+
+int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *size, uint32_t *codec)
+{
+    if (!ctx || !h_out || !size || !codec) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = ctx->last_px;
+    if (n == 0) return fail(ctx, MBK_ERR_INVALID, "no tile with quantised bytes has been computed on this ctx");
+    const uint32_t nblocks = (uint32_t)((n + mbk::kRleBlock - 1) / mbk::kRleBlock);
+    // scratch layout (all 256-byte aligned): block counts | total | run_start | run_value | out
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    // RLE is only emitted when 1 + 5*runs < 1 + n, i.e. for at most n/5 runs and n output bytes
+    const size_t max_runs = n / 5 + 1;
+    const size_t off_cnt = 0, off_tot = align(off_cnt + (size_t)nblocks * 4), off_start = align(off_tot + 8),
+                 off_val = align(off_start + max_runs * 4), off_out = align(off_val + max_runs),
+                 total_bytes = off_out + 1 + n;
+    if (n > ctx->rle_cap_px) {
+        if (ctx->d_rle) (void)hipFree(ctx->d_rle);
+        ctx->d_rle = nullptr;
+        ctx->rle_cap_px = 0;
+        MBK_HIP(ctx, hipMalloc((void **)&ctx->d_rle, total_bytes));
+        ctx->rle_cap_px = n;
+    }
+    uint32_t *d_cnt = (uint32_t *)(ctx->d_rle + off_cnt);
+    unsigned long long *d_tot = (unsigned long long *)(ctx->d_rle + off_tot);
+    uint32_t *d_start = (uint32_t *)(ctx->d_rle + off_start);
+    uint8_t *d_val = ctx->d_rle + off_val, *d_out = ctx->d_rle + off_out;
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(mbk::rle_count_kernel, dim3(nblocks), dim3(mbk::kRleBlock), 0, s, ctx->d_bytes, (uint64_t)n, d_cnt);
+    hipLaunchKernelGGL(mbk::rle_scan_kernel, dim3(1), dim3(1024), 0, s, d_cnt, nblocks, d_tot);
+    MBK_HIP(ctx, hipGetLastError());
+    unsigned long long runs = 0;
+    MBK_HIP(ctx, hipMemcpyAsync(&runs, d_tot, sizeof(runs), hipMemcpyDeviceToHost, s));
+    MBK_HIP(ctx, hipStreamSynchronize(s));
+    const uint64_t raw_size = 1 + (uint64_t)n, rle_size = 1 + 5 * (uint64_t)runs;
+    // DataChunk.Serialize keeps the first serializer (Raw) unless a later one is strictly smaller
+    const bool use_rle = rle_size < raw_size;
+    *codec = use_rle ? MBK_CODEC_RLE : MBK_CODEC_RAW;
+    *size = use_rle ? rle_size : raw_size;
+    if (cap < *size) return fail(ctx, MBK_ERR_INVALID, "output buffer too small for the serialised chunk");
+    if (use_rle) {
+        hipLaunchKernelGGL(mbk::rle_scatter_kernel, dim3(nblocks), dim3(mbk::kRleBlock), 0, s, ctx->d_bytes,
+                           (uint64_t)n, d_cnt, d_start, d_val);
+        hipLaunchKernelGGL(mbk::rle_emit_kernel, dim3((uint32_t)((runs + 255) / 256)), dim3(256), 0, s, d_start,
+                           d_val, (uint64_t)runs, (uint64_t)n, d_out);
+        MBK_HIP(ctx, hipGetLastError());
+        MBK_HIP(ctx, hipMemcpyAsync(h_out, d_out, rle_size, hipMemcpyDeviceToHost, s));
+    } else {
+        h_out[0] = MBK_CODEC_RAW;
+        MBK_HIP(ctx, hipMemcpyAsync(h_out + 1, ctx->d_bytes, n, hipMemcpyDeviceToHost, s));
+    }
+    MBK_HIP(ctx, hipStreamSynchronize(s));
+    return MBK_OK;
 }
 
 int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_t mrd,

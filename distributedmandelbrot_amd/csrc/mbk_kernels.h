@@ -499,6 +499,7 @@ __global__ __launch_bounds__(1024) void classify_blocks_kernel(TileArgs p, uint3
 struct ReduceOut {
     unsigned long long pixel_iterations;
     unsigned long long never_pixels;
+    unsigned long long run_starts;  // positions i with i == 0 or bytes[i] != bytes[i-1]
     unsigned int any_byte_not_zero;
     unsigned int any_byte_not_one;
 };
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const int32_t *__restrict__
                                                      uint64_t n, uint32_t mrd, ReduceOut *out)
 {
     const unsigned long long cap = mrd > 1u ? (unsigned long long)mrd - 1ull : 0ull;
-    unsigned long long iters = 0, never = 0;
+    unsigned long long iters = 0, never = 0, starts = 0;
     unsigned int nz = 0, no = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -527,17 +528,120 @@ __global__ __launch_bounds__(256) void reduce_kernel(const int32_t *__restrict__
             uint8_t b = bytes[i];
             nz |= (b != 0);
             no |= (b != 1);
+            starts += (i == 0 || bytes[i - 1] != b) ? 1ull : 0ull;
         }
     }
     iters = wave_sum_u64(iters);
     never = wave_sum_u64(never);
+    starts = wave_sum_u64(starts);
     const unsigned long long nzb = __ballot(nz != 0), nob = __ballot(no != 0);
     if ((threadIdx.x & 63u) == 0) {
         if (iters) atomicAdd(&out->pixel_iterations, iters);
         if (never) atomicAdd(&out->never_pixels, never);
+        if (starts) atomicAdd(&out->run_starts, starts);
         if (nzb) atomicOr(&out->any_byte_not_zero, 1u);
         if (nob) atomicOr(&out->any_byte_not_one, 1u);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-device DataChunk RLE serialiser (DataChunkSerializer.cs:56-100): run starts -> block counts ->
+// scan -> (start, value) per run -> 5-byte records.  HBM-bound: the 16 MiB tile is read twice.
+// One byte per thread, 1024-thread workgroups; run starts are found with ballots.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kRleBlock = 1024;
+
+__device__ __forceinline__ bool rle_is_start(const uint8_t *__restrict__ bytes, uint64_t i, uint64_t n)
+{
+    return i < n && (i == 0 || bytes[i] != bytes[i - 1]);
+}
+
+__global__ __launch_bounds__(1024) void rle_count_kernel(const uint8_t *__restrict__ bytes, uint64_t n,
+                                                         uint32_t *block_counts)
+{
+    __shared__ uint32_t s_cnt[16];
+    const uint64_t i = (uint64_t)blockIdx.x * kRleBlock + threadIdx.x;
+    const unsigned long long m = __ballot(rle_is_start(bytes, i, n));
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += s_cnt[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+// single workgroup: exclusive scan of the block counts in place; total -> *total_runs
+__global__ __launch_bounds__(1024) void rle_scan_kernel(uint32_t *block_counts, uint32_t nblocks,
+                                                        unsigned long long *total_runs)
+{
+    __shared__ unsigned long long s_part[1024];
+    const uint32_t per = (nblocks + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < nblocks ? lo + per : nblocks;
+    unsigned long long sum = 0;
+    for (uint32_t k = lo; k < hi; ++k) sum += block_counts[k];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const unsigned long long v = s_part[t];
+            s_part[t] = run;
+            run += v;
+        }
+        *total_runs = run;
+    }
+    __syncthreads();
+    unsigned long long run = s_part[threadIdx.x];
+    for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t v = block_counts[k];
+        block_counts[k] = (uint32_t)run;  // a tile has < 2^32 runs
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(1024) void rle_scatter_kernel(const uint8_t *__restrict__ bytes, uint64_t n,
+                                                           const uint32_t *__restrict__ block_offsets,
+                                                           uint32_t *run_start, uint8_t *run_value)
+{
+    __shared__ uint32_t s_off[16];
+    const uint64_t i = (uint64_t)blockIdx.x * kRleBlock + threadIdx.x;
+    const bool st = rle_is_start(bytes, i, n);
+    const unsigned long long m = __ballot(st);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) s_off[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = block_offsets[blockIdx.x];
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t v = s_off[w];
+            s_off[w] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    if (st) {
+        const uint32_t r = s_off[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        run_start[r] = (uint32_t)i;
+        run_value[r] = bytes[i];
+    }
+}
+
+// record r at out + 1 + 5 r: u32 runLength (little-endian), u8 value; out[0] = codec byte
+__global__ __launch_bounds__(256) void rle_emit_kernel(const uint32_t *__restrict__ run_start,
+                                                       const uint8_t *__restrict__ run_value,
+                                                       uint64_t runs, uint64_t n, uint8_t *out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) out[0] = 0x01;
+    if (r >= runs) return;
+    const uint32_t len = (uint32_t)((r + 1 < runs ? (uint64_t)run_start[r + 1] : n) - run_start[r]);
+    uint8_t *o = out + 1 + 5 * r;
+    o[0] = (uint8_t)len;
+    o[1] = (uint8_t)(len >> 8);
+    o[2] = (uint8_t)(len >> 16);
+    o[3] = (uint8_t)(len >> 24);
+    o[4] = run_value[r];
 }
 
 }  // namespace mbk

@@ -46,6 +46,7 @@ class TileStats:
     never_pixels: int
     all_bytes_zero: bool   # DataChunk.IsNeverChunk (DataChunk.cs:82)
     all_bytes_one: bool    # DataChunk.IsImmediateChunk (DataChunk.cs:87)
+    rle_runs: int = 0      # runs of equal bytes: RLE codec size = 1 + 5*rle_runs (DataChunkSerializer.cs:56-100)
 
 
 def device_count() -> int:
@@ -166,6 +167,22 @@ class MandelbrotDevice:
             counts.ctypes.data if counts is not None else None, C.byref(st)))
         return byts, counts, _stats(st)
 
+    def serialize_last(self) -> Tuple[bytes, int]:
+        """The last tile's quantised bytes exactly as DataChunk.Serialize (DataChunk.cs:173-206) would
+        write them (code byte + Raw or RLE payload, the shorter; Raw on ties), encoded on the GPU.
+        Returns (stream, codec)."""
+        cap = 1 + L.MBK_CHUNK_BYTES if not hasattr(self, "_ser_buf") else len(self._ser_buf)
+        if not hasattr(self, "_ser_buf"):
+            self._ser_buf = np.empty(cap, np.uint8)
+        size, codec = C.c_uint64(0), C.c_uint32(0)
+        st = self._lib.mbk_serialize_last(self._h, self._ser_buf.ctypes.data, cap, C.byref(size), C.byref(codec))
+        if st == L.MBK_ERR_INVALID and size.value > cap:
+            self._ser_buf = np.empty(size.value, np.uint8)
+            st = self._lib.mbk_serialize_last(self._h, self._ser_buf.ctypes.data, size.value, C.byref(size),
+                                              C.byref(codec))
+        self._check(st)
+        return self._ser_buf[:size.value].tobytes(), int(codec.value)
+
     def launch_view(self, view: View, mrd: int, *, d_counts: int = 0, d_bytes: int = 0,
                     stream: int = 0, window=None, kernel: str = "default") -> None:
         """Asynchronous launch on raw DEVICE pointers (e.g. torch tensors' data_ptr()) on ``stream``
@@ -183,4 +200,4 @@ class MandelbrotDevice:
 
 def _stats(st: L.mbk_stats) -> TileStats:
     return TileStats(float(st.kernel_ms), float(st.d2h_ms), int(st.pixel_iterations),
-                     int(st.never_pixels), bool(st.all_bytes_zero), bool(st.all_bytes_one))
+                     int(st.never_pixels), bool(st.all_bytes_zero), bool(st.all_bytes_one), int(st.rle_runs))

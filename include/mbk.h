@@ -79,6 +79,8 @@ typedef struct mbk_stats {
     uint64_t never_pixels;     /* pixels with count == 0 (never escaped) */
     uint32_t all_bytes_zero;   /* 1 iff every quantised byte == 0: DataChunk.IsNeverChunk,     DataChunk.cs:82 */
     uint32_t all_bytes_one;    /* 1 iff every quantised byte == 1: DataChunk.IsImmediateChunk, DataChunk.cs:87 */
+    uint64_t rle_runs;         /* runs of equal bytes in the quantised tile: the RLE codec (DataChunkSerializer.cs:56-100)
+                                  writes 5 bytes per run, so its size is 1 + 5*rle_runs vs 1 + n for Raw (0 if no bytes) */
 } mbk_stats;
 
 typedef struct mbk_device_info {
@@ -140,6 +142,20 @@ int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t 
  * h_counts: optional int32[16777216] (NULL to skip its D2H). */
 int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_real,
                   uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, mbk_stats *stats);
+
+/* Codec codes of DataChunkSerializer.cs (Raw :20, RLE :54). */
+#define MBK_CODEC_RAW 0x00u
+#define MBK_CODEC_RLE 0x01u
+
+/* Serialise, ON THE DEVICE, the quantised bytes of the last tile this ctx computed with
+ * MBK_WANT_BYTES (mbk_datachunk / mbk_view_compute): exactly the byte stream DataChunk.Serialize
+ * (DataChunk.cs:173-206) writes to a chunk file / the DataServer sends to the Viewer
+ * (DataServer.cs:204-220): one code byte, then the Raw payload (the n bytes) or the RLE payload
+ * (repeated u32 runLength LE + u8 value, DataChunkSerializer.cs:56-100), whichever is strictly
+ * shorter, Raw winning ties (serializer order, DataChunk.cs:165-168,190).  Only the serialised bytes
+ * cross PCIe.  h_out must hold *size <= 1 + n bytes; cap is its capacity (MBK_ERR_INVALID if too
+ * small, with *size set to the needed size). */
+int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *size, uint32_t *codec);
 
 /* Device-side reduction over int32 counts already in HBM (asynchronous part on hip_stream -- NULL =
  * the null stream -- then a stream sync): fills stats->pixel_iterations and stats->never_pixels.  Used by bench.py to turn

@@ -16,6 +16,7 @@
 
 struct Rec { unsigned long long t0, t1; unsigned hw, xcc, blk, sum; };
 
+template <int MODE>
 __global__ __launch_bounds__(256) void traced_kernel(mbk::TileArgs p, Rec *rec, const uint32_t *order)
 {
     const unsigned long long t0 = wall_clock64();
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void traced_kernel(mbk::TileArgs p, Rec *rec, 
     int32_t count = 0;
     if (lc < p.ncols && lr < p.nrows) {
         const double cr = mbk::axis_value(p.re, p.col0 + lc), ci = mbk::axis_value(p.im, p.row0 + lr);
-        count = mbk::escape_count_asm<true>(cr, ci, p.mrd);
+        count = MODE == 1 ? mbk::escape_count_group<8>(cr, ci, p.mrd) : mbk::escape_count_asm<true>(cr, ci, p.mrd);
         p.counts[(size_t)lr * p.ncols + lc] = count;
     }
     unsigned s = count > 0 ? (unsigned)count : (unsigned)(p.mrd - 1);
@@ -64,7 +65,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CHECK(hipEventRecord(e0));
-        traced_kernel<<<grid, 64 * wpw>>>(a, d, nullptr);
+        traced_kernel<0><<<grid, 64 * wpw>>>(a, d, nullptr);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -75,6 +76,23 @@ int main(int argc, char **argv)
     FILE *f = fopen(out, "wb"); fwrite(h.data(), sizeof(Rec), nw, f); fclose(f);
     printf("wrote %zu records to %s\n", nw, out);
     if (wpw == 1) {
+        // production configuration: grouped loop + classify_blocks_kernel order
+        uint32_t *dord2; CHECK(hipMalloc(&dord2, (nw + 2) * 4));
+        for (int rep = 0; rep < 3; ++rep) {
+            CHECK(hipMemset(dord2 + nw, 0, 8));
+            CHECK(hipEventRecord(e0));
+            mbk::classify_blocks_kernel<<<(grid + 1023) / 1024, 1024>>>(a, grid, 8, 32, dord2, dord2 + nw);
+            traced_kernel<1><<<grid, 64>>>(a, d, dord2);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("group8 + classify order rep %d: %.3f ms\n", rep, ms);
+        }
+        CHECK(hipMemcpy(h.data(), d, nw * sizeof(Rec), hipMemcpyDeviceToHost));
+        { FILE *g = fopen("gpurun_out/trace_w1_group.bin", "wb"); fwrite(h.data(), sizeof(Rec), nw, g); fclose(g); }
+        CHECK(hipFree(dord2));
+    }
+    if (wpw == 1 && argc > 4) {
         // EXPERIMENT (oracle ordering from the previous run's own counts): heavy blocks first.
         std::vector<std::pair<unsigned, unsigned>> key(nw);
         for (size_t i = 0; i < nw; ++i) key[h[i].blk] = {h[i].sum, h[i].blk};
@@ -88,7 +106,7 @@ int main(int argc, char **argv)
             uint32_t *dord; CHECK(hipMalloc(&dord, nw * 4)); CHECK(hipMemcpy(dord, ord.data(), nw * 4, hipMemcpyHostToDevice));
             for (int rep = 0; rep < 3; ++rep) {
                 CHECK(hipEventRecord(e0));
-                traced_kernel<<<grid, 64>>>(a, d, dord);
+                traced_kernel<0><<<grid, 64>>>(a, d, dord);
                 CHECK(hipEventRecord(e1));
                 CHECK(hipDeviceSynchronize());
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));

@@ -33,7 +33,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from distributedmandelbrot_amd import _lib
     assert C.sizeof(_lib.mbk_view) == 4 * 8 + 6 * 4
-    assert C.sizeof(_lib.mbk_stats) == 4 + 4 + 8 + 8 + 4 + 4
+    assert C.sizeof(_lib.mbk_stats) == 4 + 4 + 8 + 8 + 4 + 4 + 8
     assert C.sizeof(_lib.mbk_device_info) == 128 + 64 + 4 * 3 + 4 + 8
 
 
