@@ -47,6 +47,9 @@ WORKLOADS = {
     # diagnostics (not BASELINE configs): uniform all-in-set tile = pure loop throughput, no divergence
     "inset": (-0.2, -0.1, 0.2, 4096, 4096, 1000, "4096x4096 inside the main cardioid (every pixel runs mrd-1 steps)"),
     "exterior": (-2.0, -2.0, 1.0, 4096, 4096, 1000, "DataChunk (4,0,0): every pixel escapes within 3 steps"),
+    # BASELINE configs[3]: centre/span are not given there; SURVEY 8(d) proposes centre -0.745+0.11i, span 0.02
+    "cfg4": (-0.755, 0.10, 0.02, 16384, 16384, 50000,
+             "16384x16384 seahorse valley (centre -0.745+0.11i, span 0.02), mrd 50000 -- use --precision f32"),
 }
 FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
 # fp64-rate VALU issue slots each kernel spends per pixel-iteration (v_cmp costs a full slot on gfx950):
@@ -61,6 +64,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="default")
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
+                    help="f32 = BASELINE cfg4's fp32 kernel variant (not in the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="tiles in flight per GPU: steps are issued round-robin on this many HIP streams "
@@ -68,7 +73,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(workload):
+def cpu_baseline(workload, precision="f64"):
     """Time the C oracle (oracle/mandel_oracle.c, -ffp-contract=off) on the host cores."""
     from oracle.oracle import COracle
     sr, si, rng, w, h, mrd, _ = workload
@@ -80,12 +85,13 @@ def cpu_baseline(workload):
     t0 = time.perf_counter()
     total = 0
     if stride == 1:
-        _, _, total = o.view(sr, si, rng, rng, w, h, mrd, want_counts=False, want_bytes=False, nthreads=cores)
+        _, _, total = o.view(sr, si, rng, rng, w, h, mrd, want_counts=False, want_bytes=False, nthreads=cores,
+                             precision=precision)
         sample = f"the whole {w}x{h} tile, all rows"
     else:
         for win in bands:
             total += o.view(sr, si, rng, rng, w, h, mrd, window=win, want_counts=False,
-                            want_bytes=False, nthreads=cores)[2]
+                            want_bytes=False, nthreads=cores, precision=precision)[2]
         sample = f"every {stride}th 8-row band of the {w}x{h} tile ({len(bands) * 8} rows)"
     dt = time.perf_counter() - t0
     return {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
@@ -164,7 +170,7 @@ def main():
             i = turn[0] % nstreams
             turn[0] += 1
             dev.launch_view(view, mrd, d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
-                            kernel=args.kernel)
+                            kernel=args.kernel, precision=args.precision)
             return streams[i]
 
         def sync():
@@ -230,7 +236,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.precision,
             "data": "synthetic (coordinates generated in-kernel from the view origin and stride; no RNG)",
             "config": {"workload": f"{args.workload}: {desc}; one tile per GPU per step, int32 counts "
                                    "written to resident HBM", "kernel": args.kernel,
@@ -257,7 +263,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline and not fake:
-            rec["cpu_baseline"] = cpu_baseline(workload)
+            rec["cpu_baseline"] = cpu_baseline(workload, args.precision)
         elif world == 1 and fake:
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)

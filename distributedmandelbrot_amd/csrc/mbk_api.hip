@@ -38,6 +38,8 @@ struct mbk_ctx {
     uint32_t *d_order = nullptr;     // kQueueRing dispatch-order lists (+2 cursors each)
     size_t order_cap = 0;            // regions per list
     size_t last_px = 0;              // pixels of the last tile computed with bytes (for mbk_serialize_last)
+    double *d_smooth = nullptr;      // smooth-colouring output of the synchronous API
+    size_t smooth_cap_px = 0;
     uint8_t *d_rle = nullptr;        // RLE scratch: block counts | run starts | run values | output stream
     size_t rle_cap_px = 0;
     unsigned queue_turn = 0;
@@ -129,7 +131,7 @@ static uint32_t coprime_multiplier(uint32_t n)
     }
 }
 
-static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling)
+static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling, bool f32 = false)
 {
     if (!v) return fail(ctx, MBK_ERR_INVALID, "view is NULL");
     if (v->width == 0 || v->height == 0) return fail(ctx, MBK_ERR_INVALID, "empty view");
@@ -140,28 +142,33 @@ static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling)
         return fail(ctx, MBK_ERR_INVALID, "window larger than 2^31 pixels");
     const double vals[6] = {v->start_r, v->start_i, v->range_r, v->range_i,
                             v->start_r + v->range_r, v->start_i + v->range_i};
+    const double max_coord = f32 ? 0x1p60 : kMaxCoord;
     for (double x : vals)
-        if (!std::isfinite(x) || std::fabs(x) > kMaxCoord)
-            return fail(ctx, MBK_ERR_INVALID, "view coordinates must be finite and |x| <= 2^500");
+        if (!std::isfinite(x) || std::fabs(x) > max_coord)
+            return fail(ctx, MBK_ERR_INVALID, f32 ? "view coordinates must be finite and |x| <= 2^60 (fp32)"
+                                                  : "view coordinates must be finite and |x| <= 2^500");
     bool safe = false;
     const Axis im = make_axis(v->start_i, v->range_i, v->height);
     for (uint32_t r = 0; r < v->nrows && !safe; ++r) {
-        const double ci = std::fabs(axis_value_host(im, v->row0 + r));
-        if (ci != 0.0 && ci < kSafeImagMin) safe = true;
+        const double ci64 = axis_value_host(im, v->row0 + r);
+        // the same argument in binary32: a subnormal product matters only below 2^-126 * 2^24
+        const double ci = f32 ? std::fabs((double)(float)ci64) : std::fabs(ci64);
+        if (ci != 0.0 && ci < (f32 ? 0x1p-100 : kSafeImagMin)) safe = true;
     }
     *safe_doubling = safe;
     return MBK_OK;
 }
 
 static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t flags,
-                       int32_t *d_counts, uint8_t *d_bytes, hipStream_t stream)
+                       int32_t *d_counts, uint8_t *d_bytes, hipStream_t stream, double *d_smooth = nullptr)
 {
     bool safe = false;
-    int rc = validate_view(ctx, v, &safe);
+    const bool f32 = (flags & MBK_PRECISION_F32) != 0;
+    int rc = validate_view(ctx, v, &safe, f32);
     if (rc != MBK_OK) return rc;
     if (mrd > 0x7fffffffu) return fail(ctx, MBK_ERR_INVALID, "mrd must fit int32 (calc_mb_value returns int32)");
     const bool wc = (flags & MBK_WANT_COUNTS) != 0, wb = (flags & MBK_WANT_BYTES) != 0;
-    if (!wc && !wb) return fail(ctx, MBK_ERR_INVALID, "flags select no output");
+    if (!wc && !wb && !d_smooth) return fail(ctx, MBK_ERR_INVALID, "flags select no output");
     if (wc && !d_counts) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_COUNTS with NULL counts pointer");
     if (wb && !d_bytes) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_BYTES with NULL bytes pointer");
     if (wb && mrd == 0) return fail(ctx, MBK_ERR_INVALID, "mrd == 0 has no quantised form (division by zero)");
@@ -182,8 +189,13 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     a.order = nullptr;
     a.counts = wc ? d_counts : nullptr;
     a.bytes = wb ? d_bytes : nullptr;
+    a.smooth = d_smooth;
 
     const uint32_t kernel = flags & MBK_KERNEL_MASK;
+    if (d_smooth && (f32 || kernel == MBK_KERNEL_SIMPLE || kernel == MBK_KERNEL_REFILL))
+        return fail(ctx, MBK_ERR_INVALID, "smooth colouring is implemented by the fp64 asm / group kernels only");
+    if (f32 && (kernel == MBK_KERNEL_SIMPLE || kernel == MBK_KERNEL_REFILL))
+        return fail(ctx, MBK_ERR_INVALID, "MBK_PRECISION_F32 is implemented by the asm / group kernels only");
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
         case MBK_KERNEL_GROUP:
@@ -198,6 +210,7 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
                 if (grid.x > ctx->order_cap) {
                     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_rle) (void)hipFree(ctx->d_rle);
+    if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
                     ctx->d_order = nullptr;
                     ctx->order_cap = 0;
                     MBK_HIP(ctx, hipMalloc((void **)&ctx->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t) * kQueueRing));
@@ -211,21 +224,27 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
                 a.order = ord;
             }
             // dynamic LDS is never touched: it only caps how many workgroups a CU admits
-            if (safe)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<false, 0>), grid, block, ctx->lds_pad, stream, a);
+            if (f32 && safe)
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, ctx->lds_pad, stream, a);
+            else if (f32 && kernel == MBK_KERNEL_ASM)
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, ctx->lds_pad, stream, a);
+            else if (f32)
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, ctx->lds_pad, stream, a);
+            else if (safe)
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, ctx->lds_pad, stream, a);
             else if (kernel == MBK_KERNEL_ASM)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 0>), grid, block, ctx->lds_pad, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, ctx->lds_pad, stream, a);
             else if (ctx->group_steps == 8)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 8>), grid, block, ctx->lds_pad, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, ctx->lds_pad, stream, a);
             else
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 4>), grid, block, ctx->lds_pad, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, ctx->lds_pad, stream, a);
             break;
         }
         case MBK_KERNEL_REFILL: {
             if (mrd < 2) {  // nothing to iterate: the plain kernel writes the zeros
                 a.blocks_x = (v->ncols + 31u) / 32u;
                 const dim3 grid(a.blocks_x * ((v->nrows + 7u) / 8u)), block(256);
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<true, 0>), grid, block, 0, stream, a);
+                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, 0, stream, a);
                 break;
             }
             const uint32_t nblocks = ((v->ncols + 7u) / 8u) * ((v->nrows + 7u) / 8u);
@@ -378,6 +397,7 @@ void mbk_destroy(mbk_ctx *ctx)
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_rle) (void)hipFree(ctx->d_rle);
+    if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
     if (ctx->h_red) (void)hipHostFree(ctx->h_red);
     if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
     if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
@@ -453,14 +473,14 @@ int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t 
     if (wc && !h_counts) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_COUNTS with NULL counts pointer");
     if (wb && !h_bytes) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_BYTES with NULL bytes pointer");
     bool dummy;
-    int rc = validate_view(ctx, view, &dummy);
+    int rc = validate_view(ctx, view, &dummy, (flags & MBK_PRECISION_F32) != 0);
     if (rc != MBK_OK) return rc;
     const size_t px = (size_t)view->ncols * view->nrows;
     rc = ensure_buffers(ctx, px);
     if (rc != MBK_OK) return rc;
     // counts are always produced on the device (they feed the stats reduction); only what the
     // caller asked for crosses PCIe.
-    const uint32_t dev_flags = (flags & MBK_KERNEL_MASK) | MBK_WANT_COUNTS | (wb ? MBK_WANT_BYTES : 0u);
+    const uint32_t dev_flags = (flags & (MBK_KERNEL_MASK | MBK_PRECISION_F32)) | MBK_WANT_COUNTS | (wb ? MBK_WANT_BYTES : 0u);
     MBK_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     rc = launch_tile(ctx, view, mrd, dev_flags, ctx->d_counts, ctx->d_bytes, ctx->stream);
     if (rc != MBK_OK) return rc;
@@ -507,6 +527,56 @@ int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_rea
     return mbk_view_compute(ctx, &v, mrd, flags, h_counts, h_bytes, stats);
 }
 
+int mbk_view_launch_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                           int32_t *d_counts, double *d_smooth, void *hip_stream)
+{
+    if (!ctx || !d_smooth) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t f = (flags & (MBK_KERNEL_MASK | MBK_PRECISION_F32)) | (d_counts ? MBK_WANT_COUNTS : 0u);
+    return launch_tile(ctx, view, mrd, f, d_counts, nullptr, (hipStream_t)hip_stream, d_smooth);
+}
+
+int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                            int32_t *h_counts, double *h_smooth, mbk_stats *stats)
+{
+    if (!ctx || !view || !h_smooth) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    bool dummy;
+    int rc = validate_view(ctx, view, &dummy);
+    if (rc != MBK_OK) return rc;
+    const size_t px = (size_t)view->ncols * view->nrows;
+    rc = ensure_buffers(ctx, px);
+    if (rc != MBK_OK) return rc;
+    if (px > ctx->smooth_cap_px) {
+        if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
+        ctx->d_smooth = nullptr;
+        ctx->smooth_cap_px = 0;
+        MBK_HIP(ctx, hipMalloc((void **)&ctx->d_smooth, px * sizeof(double)));
+        ctx->smooth_cap_px = px;
+    }
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    rc = launch_tile(ctx, view, mrd, (flags & MBK_KERNEL_MASK) | MBK_WANT_COUNTS, ctx->d_counts, nullptr,
+                     ctx->stream, ctx->d_smooth);
+    if (rc != MBK_OK) return rc;
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    rc = launch_reduce(ctx, ctx->d_counts, nullptr, px, mrd, ctx->stream);
+    if (rc != MBK_OK) return rc;
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
+    MBK_HIP(ctx, hipMemcpyAsync(h_smooth, ctx->d_smooth, px * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (h_counts)
+        MBK_HIP(ctx, hipMemcpyAsync(h_counts, ctx->d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MBK_HIP(ctx, hipEventRecord(ctx->ev_c1, ctx->stream));
+    MBK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_px = 0;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev_k0, ctx->ev_k1));
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->d2h_ms, ctx->ev_c0, ctx->ev_c1));
+        fill_stats_from_reduce(ctx, stats, false);
+    }
+    return MBK_OK;
+}
+
 int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *size, uint32_t *codec)
 {
     if (!ctx || !h_out || !size || !codec) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
@@ -523,6 +593,7 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
                  total_bytes = off_out + 1 + n;
     if (n > ctx->rle_cap_px) {
         if (ctx->d_rle) (void)hipFree(ctx->d_rle);
+    if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
         ctx->d_rle = nullptr;
         ctx->rle_cap_px = 0;
         MBK_HIP(ctx, hipMalloc((void **)&ctx->d_rle, total_bytes));

@@ -48,6 +48,7 @@ struct TileArgs {
     const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel)
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
+    double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value
 };
 
 // np.linspace sample k (numpy/_core/function_base.py): two roundings, endpoint pinned.
@@ -74,6 +75,15 @@ __device__ __forceinline__ uint8_t quantise(int32_t count, int32_t mrd, uint32_t
     }
     uint32_t x = (uint32_t)count * 256u + (uint32_t)mrd - 1u;
     return (uint8_t)(x / (uint32_t)mrd);
+}
+
+// BASELINE config 5 (NOT in the reference): continuous ("smooth") escape-time value at the
+// reference's own bailout, nu = n + 1 - log2(0.5 * ln |z_n|^2) for an escaped pixel (n = escape index,
+// |z_n|^2 = the value that tripped `>= 4`), 0 for a pixel that never escaped.  The integer information
+// is the exact count; only log/log2 are subject to libm-vs-ocml rounding (tests allow 1e-12).
+__device__ __forceinline__ double smooth_value(int32_t count, double m)
+{
+    return count > 0 ? (double)count + 1.0 - log2(0.5 * log(m)) : 0.0;
 }
 
 // The reference loop for one pixel.  kFmaDouble selects how fl(2*zr*zi + ci) is formed.
@@ -130,308 +140,54 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
     if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Kernel "asm": same pixel mapping as "simple", but the escape loop is a hand-scheduled gfx950
-// instruction stream.  Why: the compiler's structured-CFG loop spends ~14 SALU instructions and 3
-// branches per iteration on EXEC bookkeeping; a CU has ONE scalar pipe for its four SIMDs, so at 8
-// waves/SIMD the compiler loop is scalar-issue bound (measured 1.7 T pixel-iter/s, ~72 cycles per
-// wave-iteration) instead of fp64-VALU bound (7 x 4 cycles).  This loop issues, per iteration,
-// 7 fp64 VALU + 1 v_cmp + 1 branch, plus 3 SALU per FOUR iterations:
-//   * the iteration counter lives in an SGPR (uniform) and is bumped once per 4 unrolled steps;
-//   * "some lane escaped" is the rare path: `s_cbranch_vccnz` jumps out of line, where the escaped
-//     lanes record the step index and leave EXEC; when EXEC empties the wave leaves the loop at
-//     once (the wavefront-level early exit);
-//   * v_cmp_le_f64 vcc, 4.0, m implements `m >= 4` with IEEE semantics (false for NaN).
-// kFmaDouble = false swaps fma(2, zr*zi, ci) for the literal (zr+zr)*zi + ci (8 fp64 ops).
-// ---------------------------------------------------------------------------------------------
-#define MBK_STEP_HEAD_FMA                                  \
-    "v_add_f64 %[t], %[a], -%[b]\n"                        \
-    "v_mul_f64 %[p], %[zr], %[zi]\n"                       \
-    "v_add_f64 %[zr], %[t], %[cr]\n"                       \
-    "v_fma_f64 %[zi], %[p], 2.0, %[ci]\n"
-#define MBK_STEP_HEAD_SAFE                                 \
-    "v_add_f64 %[t], %[a], -%[b]\n"                        \
-    "v_add_f64 %[p], %[zr], %[zr]\n"                       \
-    "v_mul_f64 %[p], %[p], %[zi]\n"                        \
-    "v_add_f64 %[zr], %[t], %[cr]\n"                       \
-    "v_add_f64 %[zi], %[p], %[ci]\n"
-#define MBK_STEP_TAIL(ID)                                  \
-    "v_mul_f64 %[a], %[zr], %[zr]\n"                       \
-    "v_mul_f64 %[b], %[zi], %[zi]\n"                       \
-    "v_add_f64 %[m], %[a], %[b]\n"                         \
-    "v_cmp_le_f64 vcc, 4.0, %[m]\n"                        \
-    "s_cbranch_vccnz .Lesc" ID "_%=\n"                     \
-    ".Lcont" ID "_%=:\n"
-// out-of-line: lanes in VCC escaped at step N+INC
-#define MBK_ESCAPE(ID, INC)                                \
-    ".Lesc" ID "_%=:\n"                                    \
-    "s_add_u32 %[k], %[n], " INC "\n"                      \
-    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
-    "v_mov_b32 %[cnt], %[k]\n"                             \
-    "s_andn2_b64 exec, %[tmp], vcc\n"                      \
-    "s_cbranch_scc1 .Lcont" ID "_%=\n"                     \
-    "s_branch .Ldone_%=\n"
-#define MBK_LOOP_ASM(HEAD)                                 \
-    "s_mov_b64 %[save], exec\n"                            \
-    "s_mov_b32 %[n], %[n0]\n"                              \
-    "s_cmp_ge_u32 %[n], %[limit4]\n"                       \
-    "s_cbranch_scc1 .Ltail_%=\n"                           \
-    ".Lmain_%=:\n"                                         \
-    HEAD MBK_STEP_TAIL("1") HEAD MBK_STEP_TAIL("2")        \
-    HEAD MBK_STEP_TAIL("3") HEAD MBK_STEP_TAIL("4")        \
-    "s_add_u32 %[n], %[n], 4\n"                            \
-    "s_cmp_lt_u32 %[n], %[limit4]\n"                       \
-    "s_cbranch_scc1 .Lmain_%=\n"                           \
-    ".Ltail_%=:\n"                                         \
-    "s_cmp_ge_u32 %[n], %[total]\n"                        \
-    "s_cbranch_scc1 .Ldone_%=\n"                           \
-    ".Ltloop_%=:\n"                                        \
-    HEAD MBK_STEP_TAIL("T")                                \
-    "s_add_u32 %[n], %[n], 1\n"                            \
-    "s_cmp_lt_u32 %[n], %[total]\n"                        \
-    "s_cbranch_scc1 .Ltloop_%=\n"                          \
-    "s_branch .Ldone_%=\n"                                 \
-    MBK_ESCAPE("1", "1") MBK_ESCAPE("2", "2") MBK_ESCAPE("3", "3") MBK_ESCAPE("4", "4")  \
-    MBK_ESCAPE("T", "1")                                   \
-    ".Ldone_%=:\n"                                         \
-    "s_mov_b64 exec, %[save]\n"
+// The hand-scheduled loops (kernels "asm" and "group") live in mbk_loops.inc, instantiated for
+// double (the reference's arithmetic) and float (cfg4's fp32 variant) as overloads.
+#define MBK_T double
+#define MBK_F "f64"
+#include "mbk_loops.inc"
+#undef MBK_T
+#undef MBK_F
+#define MBK_T float
+#define MBK_F "f32"
+#include "mbk_loops.inc"
+#undef MBK_T
+#undef MBK_F
 
-// Per-step loop: runs steps n0+1 .. stop on the state (zr, zi, a = zr^2, b = zi^2); lanes that escape
-// get cnt = step index and leave; survivors keep cnt unchanged and their state advanced to `stop`.
-template <bool kFmaDouble>
-__device__ __forceinline__ void escape_steps_asm(double cr, double ci, double &zr, double &zi, double &a,
-                                                 double &b, int32_t &cnt, uint32_t n0, uint32_t stop)
-{
-    double t, p, m;
-    const uint32_t total = stop;                         // uniform
-    const uint32_t limit4 = n0 + ((stop - n0) & ~3u);    // whole 4-step trips
-    uint32_t n, k;
-    unsigned long long save, tmp;
-    if (kFmaDouble) {
-        asm volatile(MBK_LOOP_ASM(MBK_STEP_HEAD_FMA)
-                     : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
-                       [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
-                       [save] "=&s"(save), [tmp] "=&s"(tmp)
-                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4), [n0] "s"(n0)
-                     : "vcc", "scc");
-    } else {
-        asm volatile(MBK_LOOP_ASM(MBK_STEP_HEAD_SAFE)
-                     : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),
-                       [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),
-                       [save] "=&s"(save), [tmp] "=&s"(tmp)
-                     : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit4] "s"(limit4), [n0] "s"(n0)
-                     : "vcc", "scc");
-    }
-}
 
-template <bool kFmaDouble>
-__device__ __forceinline__ int32_t escape_count_asm(double cr, double ci, int32_t mrd)
-{
-    double zr = cr, zi = ci;
-    double a = zr * zr, b = zi * zi;
-    int32_t cnt = 0;
-    escape_steps_asm<kFmaDouble>(cr, ci, zr, zi, a, b, cnt, 0u, mrd > 1 ? (uint32_t)mrd - 1u : 0u);
-    return cnt;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Grouped bailout test ("group" loop).  The bailout compare costs a full fp64 issue slot (v_cmp writes
-// an SGPR pair: 4.4 cycles, measured) and needs m = a + b, another slot: 2 of the 8 slots of a step.
-// Once |z|^2 >= 4 the orbit cannot come back below 4 (for |c| <= 2 - 1e-9:
-// |z'| >= |z|^2 - |c| >= 2 with margin over rounding; for |c| >= 2 + 1e-9 it escapes at step 1 and
-// |z| >= |c| grows; it ends in inf and then NaN), so it is enough to test after every G = 4 steps
-// with a NaN-inclusive compare (v_cmp_ngt_f64 vcc, 4.0, m == !(4 > m)), and to find the exact step
-// afterwards: the four unchecked steps run on a scratch register set and leave the group's start
-// state intact, so the lanes that tripped the test REPLAY those four steps with the exact per-step
-// IEEE test (v_cmp_le_f64 4.0 <= m) and record the first hit.  Result: 6 fp64 VALU per step + 2 per
-// group = 6.5 slots per step instead of 8, bit-identical counts.
-// Waves that contain a pixel with | |c|^2 - 4 | < 1e-9 (the one place where "stays >= 4" could be
-// spoiled by rounding) take the per-step loop instead (tile_asm_kernel's `risky` branch).
-// Register sets: A = (zr, zi, a, b) and B = (zr2, zi2, a2, b2) alternate as group start/end; T is the
-// scratch set.  One loop trip = group A->B + group B->A = 8 steps.
-// ---------------------------------------------------------------------------------------------
-#define MBK_G_STEP(ZRS, ZIS, AS, BS, ZRD, ZID, AD, BD)     \
-    "v_add_f64 %[t], " AS ", -" BS "\n"                    \
-    "v_mul_f64 %[p], " ZRS ", " ZIS "\n"                   \
-    "v_add_f64 " ZRD ", %[t], %[cr]\n"                     \
-    "v_fma_f64 " ZID ", %[p], 2.0, %[ci]\n"                \
-    "v_mul_f64 " AD ", " ZRD ", " ZRD "\n"                 \
-    "v_mul_f64 " BD ", " ZID ", " ZID "\n"
-#define MBK_G_A2T MBK_G_STEP("%[zr]", "%[zi]", "%[a]", "%[b]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
-#define MBK_G_B2T MBK_G_STEP("%[zr2]", "%[zi2]", "%[a2]", "%[b2]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
-#define MBK_G_T2T MBK_G_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
-#define MBK_G_T2A MBK_G_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zr]", "%[zi]", "%[a]", "%[b]")
-#define MBK_G_T2B MBK_G_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zr2]", "%[zi2]", "%[a2]", "%[b2]")
-// four unchecked steps (FIRST, T2T, T2T, LAST), then the NaN-inclusive group test on the end set
-#define MBK_G_GROUP(FIRST, LAST, AD, BD, ID)               \
-    FIRST MBK_G_T2T MBK_G_T2T LAST                         \
-    "v_add_f64 %[m], " AD ", " BD "\n"                     \
-    "v_cmp_ngt_f64 vcc, 4.0, %[m]\n"                       \
-    "s_cbranch_vccnz .Lgrep" ID "_%=\n"                    \
-    ".Lgcont" ID "_%=:\n"
-// one replayed step (STEP writes set T) with the exact test; hits record clock n+J and leave EXEC
-#define MBK_G_REPLAY_STEP(STEP, J)                         \
-    STEP                                                   \
-    "v_add_f64 %[m], %[at], %[bt]\n"                       \
-    "v_cmp_le_f64 vcc, 4.0, %[m]\n"                        \
-    "s_add_u32 %[k], %[n], " J "\n"                        \
-    "s_or_b64 %[esc], %[esc], vcc\n"                       \
-    "s_and_saveexec_b64 %[tmp2], vcc\n"                    \
-    "v_mov_b32 %[cnt], %[k]\n"                             \
-    "s_andn2_b64 exec, %[tmp2], vcc\n"
-// replay of a whole group from its intact start set
-#define MBK_G_REPLAY(FIRST, ID, J1, J2, J3, J4)            \
-    ".Lgrep" ID "_%=:\n"                                   \
-    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
-    "s_mov_b64 %[esc], 0\n"                                \
-    MBK_G_REPLAY_STEP(FIRST, J1) MBK_G_REPLAY_STEP(MBK_G_T2T, J2) \
-    MBK_G_REPLAY_STEP(MBK_G_T2T, J3) MBK_G_REPLAY_STEP(MBK_G_T2T, J4) \
-    "s_andn2_b64 exec, %[tmp], %[esc]\n"                   \
-    "s_cbranch_scc1 .Lgcont" ID "_%=\n"                    \
-    "s_branch .Lgdone_%=\n"
-#define MBK_G_LOOP                                         \
-    "s_mov_b64 %[save], exec\n"                            \
-    "s_mov_b32 %[n], %[n0]\n"                              \
-    "s_cmp_ge_u32 %[n], %[limit8]\n"                          \
-    "s_cbranch_scc1 .Lgtail_%=\n"                          \
-    ".Lgmain_%=:\n"                                        \
-    MBK_G_GROUP(MBK_G_A2T, MBK_G_T2B, "%[a2]", "%[b2]", "1") \
-    MBK_G_GROUP(MBK_G_B2T, MBK_G_T2A, "%[a]", "%[b]", "2")    \
-    "s_add_u32 %[n], %[n], 8\n"                            \
-    "s_cmp_lt_u32 %[n], %[limit8]\n"                       \
-    "s_cbranch_scc1 .Lgmain_%=\n"                          \
-    ".Lgtail_%=:\n"                                        \
-    "s_cmp_ge_u32 %[n], %[total]\n"                        \
-    "s_cbranch_scc1 .Lgdone_%=\n"                          \
-    ".Lgtloop_%=:\n"                                       \
-    MBK_STEP_HEAD_FMA MBK_STEP_TAIL("GT")                  \
-    "s_add_u32 %[n], %[n], 1\n"                            \
-    "s_cmp_lt_u32 %[n], %[total]\n"                        \
-    "s_cbranch_scc1 .Lgtloop_%=\n"                         \
-    "s_branch .Lgdone_%=\n"                                \
-    MBK_G_REPLAY(MBK_G_A2T, "1", "1", "2", "3", "4")       \
-    MBK_G_REPLAY(MBK_G_B2T, "2", "5", "6", "7", "8")       \
-    MBK_ESCAPE("GT", "1")                                  \
-    ".Ldone_%=:\n"                                         \
-    ".Lgdone_%=:\n"                                        \
-    "s_mov_b64 exec, %[save]\n"
-
-// ---- same scheme with 8 steps per group (6.25 slots per step; one trip = 16 steps) -------------
-#define MBK_G_GROUP8(FIRST, LAST, AD, BD, ID)              \
-    FIRST MBK_G_T2T MBK_G_T2T MBK_G_T2T MBK_G_T2T MBK_G_T2T MBK_G_T2T LAST \
-    "v_add_f64 %[m], " AD ", " BD "\n"                     \
-    "v_cmp_ngt_f64 vcc, 4.0, %[m]\n"                       \
-    "s_cbranch_vccnz .Lgrep" ID "_%=\n"                    \
-    ".Lgcont" ID "_%=:\n"
-#define MBK_G_REPLAY8(FIRST, ID, J1, J2, J3, J4, J5, J6, J7, J8) \
-    ".Lgrep" ID "_%=:\n"                                   \
-    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
-    "s_mov_b64 %[esc], 0\n"                                \
-    MBK_G_REPLAY_STEP(FIRST, J1) MBK_G_REPLAY_STEP(MBK_G_T2T, J2) \
-    MBK_G_REPLAY_STEP(MBK_G_T2T, J3) MBK_G_REPLAY_STEP(MBK_G_T2T, J4) \
-    MBK_G_REPLAY_STEP(MBK_G_T2T, J5) MBK_G_REPLAY_STEP(MBK_G_T2T, J6) \
-    MBK_G_REPLAY_STEP(MBK_G_T2T, J7) MBK_G_REPLAY_STEP(MBK_G_T2T, J8) \
-    "s_andn2_b64 exec, %[tmp], %[esc]\n"                   \
-    "s_cbranch_scc1 .Lgcont" ID "_%=\n"                    \
-    "s_branch .Lgdone_%=\n"
-#define MBK_G_LOOP8                                        \
-    "s_mov_b64 %[save], exec\n"                            \
-    "s_mov_b32 %[n], %[n0]\n"                              \
-    "s_cmp_ge_u32 %[n], %[limit8]\n"                          \
-    "s_cbranch_scc1 .Lgtail_%=\n"                          \
-    ".Lgmain_%=:\n"                                        \
-    MBK_G_GROUP8(MBK_G_A2T, MBK_G_T2B, "%[a2]", "%[b2]", "1") \
-    MBK_G_GROUP8(MBK_G_B2T, MBK_G_T2A, "%[a]", "%[b]", "2")   \
-    "s_add_u32 %[n], %[n], 16\n"                           \
-    "s_cmp_lt_u32 %[n], %[limit8]\n"                       \
-    "s_cbranch_scc1 .Lgmain_%=\n"                          \
-    ".Lgtail_%=:\n"                                        \
-    "s_cmp_ge_u32 %[n], %[total]\n"                        \
-    "s_cbranch_scc1 .Lgdone_%=\n"                          \
-    ".Lgtloop_%=:\n"                                       \
-    MBK_STEP_HEAD_FMA MBK_STEP_TAIL("GT")                  \
-    "s_add_u32 %[n], %[n], 1\n"                            \
-    "s_cmp_lt_u32 %[n], %[total]\n"                        \
-    "s_cbranch_scc1 .Lgtloop_%=\n"                         \
-    "s_branch .Lgdone_%=\n"                                \
-    MBK_G_REPLAY8(MBK_G_A2T, "1", "1", "2", "3", "4", "5", "6", "7", "8")       \
-    MBK_G_REPLAY8(MBK_G_B2T, "2", "9", "10", "11", "12", "13", "14", "15", "16") \
-    MBK_ESCAPE("GT", "1")                                  \
-    ".Ldone_%=:\n"                                         \
-    ".Lgdone_%=:\n"                                        \
-    "s_mov_b64 exec, %[save]\n"
-
-// Grouped loop on an existing state: steps n0+1 .. total (see escape_steps_asm for the contract).
-template <int kGroup = 4>
-__device__ __forceinline__ void escape_steps_group(double cr, double ci, double &zr, double &zi, double &a,
-                                                   double &b, int32_t &cnt, uint32_t n0, uint32_t total)
-{
-    double zr2, zi2, a2, b2, zrt, zit, at, bt, t, p, m;
-    const uint32_t limit8 = n0 + ((total - n0) & (kGroup == 8 ? ~15u : ~7u));  // whole trips only
-    uint32_t n, k;
-    unsigned long long save, tmp, tmp2, esc;
-#define MBK_G_OPERANDS                                                                          \
-                 : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt),  \
-                   [zr2] "=&v"(zr2), [zi2] "=&v"(zi2), [a2] "=&v"(a2), [b2] "=&v"(b2),            \
-                   [zrt] "=&v"(zrt), [zit] "=&v"(zit), [at] "=&v"(at), [bt] "=&v"(bt),            \
-                   [t] "=&v"(t), [p] "=&v"(p), [m] "=&v"(m), [n] "=&s"(n), [k] "=&s"(k),          \
-                   [save] "=&s"(save), [tmp] "=&s"(tmp), [tmp2] "=&s"(tmp2), [esc] "=&s"(esc)     \
-                 : [cr] "v"(cr), [ci] "v"(ci), [total] "s"(total), [limit8] "s"(limit8), [n0] "s"(n0) \
-                 : "vcc", "scc"
-    if (kGroup == 8) {
-        asm volatile(MBK_G_LOOP8 MBK_G_OPERANDS);
-    } else {
-        asm volatile(MBK_G_LOOP MBK_G_OPERANDS);
-    }
-#undef MBK_G_OPERANDS
-}
-
-// Default pixel routine: the first kExactSteps steps with the per-step test (most escaping pixels leave
-// here and never pay a group + replay), the rest in groups.
-template <int kGroup = 4>
-__device__ __forceinline__ int32_t escape_count_group(double cr, double ci, int32_t mrd)
-{
-    constexpr uint32_t kExactSteps = 8;
-    double zr = cr, zi = ci;
-    double a = zr * zr, b = zi * zi;
-    int32_t cnt = 0;
-    const uint32_t total = mrd > 1 ? (uint32_t)mrd - 1u : 0u;
-    const uint32_t first = total < kExactSteps ? total : kExactSteps;
-    escape_steps_asm<true>(cr, ci, zr, zi, a, b, cnt, 0u, first);
-    if (cnt == 0 && total > first) escape_steps_group<kGroup>(cr, ci, zr, zi, a, b, cnt, first, total);
-    return cnt;
-}
-
-template <bool kFmaDouble, int kGroup = 0>
+// T = double: the reference's arithmetic.  T = float: the fp32 variant (coordinates are generated in
+// fp64 exactly as for the fp64 path and then rounded once to fp32; the loop is strict fp32).
+template <typename T, bool kFmaDouble, int kGroup = 0>
 __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    // Dispatch order != image order: consecutive workgroup ids are scattered over the tile by a
-    // multiplicative permutation (perm_mul coprime to the grid size), so the long-running in-set
-    // blocks do not arrive in clusters.
+    // Dispatch order != image order when an order list is given (heavy-first, classify_blocks_kernel)
+    // or perm_mul != 1 (multiplicative permutation, coprime to the grid size).
     const uint32_t blk = p.order ? p.order[blockIdx.x]
                                  : (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
     const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
     const uint32_t lc = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);  // one 8x8 block per wave
     const uint32_t lr = by * 8u + (lane >> 3);
     if (lc >= p.ncols || lr >= p.nrows) return;
-    const double cr = axis_value(p.re, p.col0 + lc);
-    const double ci = axis_value(p.im, p.row0 + lr);
+    const T cr = (T)axis_value(p.re, p.col0 + lc);
+    const T ci = (T)axis_value(p.im, p.row0 + lr);
     int32_t count;
+    T m = 0;  // |z|^2 at the escaping step (only meaningful when count > 0)
     if (kGroup != 0 && kFmaDouble) {
         // the grouped test relies on "|z|^2 >= 4 stays >= 4"; only |c| within rounding of 2 could
         // spoil that, so any wave touching that ring takes the per-step loop (wave-uniform branch)
-        const double c2 = cr * cr + ci * ci;
-        const bool risky = __any(c2 > 4.0 - 1e-9 && c2 < 4.0 + 1e-9) != 0;
-        count = risky ? escape_count_asm<true>(cr, ci, p.mrd)
-                      : escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd);
+        const T c2 = cr * cr + ci * ci;
+        const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
+        const bool risky = __any(c2 > (T)4 - margin && c2 < (T)4 + margin) != 0;
+        count = risky ? escape_count_asm<true>(cr, ci, p.mrd, &m)
+                      : escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd, &m);
     } else {
-        count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd);
+        count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd, &m);
     }
     const size_t o = (size_t)lr * p.ncols + lc;
     if (p.counts) p.counts[o] = count;
     if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
+    if (p.smooth) p.smooth[o] = smooth_value(count, (double)m);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -110,6 +110,17 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 // Leaves when (a) no lane is left, (b) at most LIVEMIN lanes are left (enough free lanes to make a
 // refill worthwhile), (c) the clock reaches ALARM at a 4-step boundary (ALARM = mrd deadline bound,
 // pulled in to "first unrefilled escape + PATIENCE").  Escaped lanes get CNT = clock - START.
+#define MBK_RF_HEAD_FMA                                    \
+    "v_add_f64 %[t], %[a], -%[b]\n"                        \
+    "v_mul_f64 %[p], %[zr], %[zi]\n"                       \
+    "v_add_f64 %[zr], %[t], %[cr]\n"                       \
+    "v_fma_f64 %[zi], %[p], 2.0, %[ci]\n"
+#define MBK_RF_HEAD_SAFE                                   \
+    "v_add_f64 %[t], %[a], -%[b]\n"                        \
+    "v_add_f64 %[p], %[zr], %[zr]\n"                       \
+    "v_mul_f64 %[p], %[p], %[zi]\n"                        \
+    "v_add_f64 %[zr], %[t], %[cr]\n"                       \
+    "v_add_f64 %[zi], %[p], %[ci]\n"
 #define MBK_RF_STEP(ID)                                    \
     "v_mul_f64 %[a], %[zr], %[zr]\n"                       \
     "v_mul_f64 %[b], %[zi], %[zi]\n"                       \
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
             n = uniform_u32(n);
             live = uniform_u64(live);
             if (kFmaDouble) {
-                asm volatile(MBK_RF_LOOP(MBK_STEP_HEAD_FMA)
+                asm volatile(MBK_RF_LOOP(MBK_RF_HEAD_FMA)
                              : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b),
                                [cnt] "+&v"(cnt), [t] "=&v"(t), [p] "=&v"(pr), [m] "=&v"(m),
                                [n] "+&s"(n), [live] "+&s"(live), [alarm] "+&s"(alarm),
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
                                [patience] "s"(patience)
                              : "vcc", "scc");
             } else {
-                asm volatile(MBK_RF_LOOP(MBK_STEP_HEAD_SAFE)
+                asm volatile(MBK_RF_LOOP(MBK_RF_HEAD_SAFE)
                              : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b),
                                [cnt] "+&v"(cnt), [t] "=&v"(t), [p] "=&v"(pr), [m] "=&v"(m),
                                [n] "+&s"(n), [live] "+&s"(live), [alarm] "+&s"(alarm),

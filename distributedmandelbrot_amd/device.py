@@ -132,12 +132,12 @@ class MandelbrotDevice:
                           view.width, view.height, col0, row0, ncols, nrows)
 
     def compute_view(self, view: View, mrd: int, *, window=None, want_counts: bool = True,
-                     want_bytes: bool = True, kernel: str = "default",
+                     want_bytes: bool = True, kernel: str = "default", precision: str = "f64",
                      out_counts: Optional[np.ndarray] = None, out_bytes: Optional[np.ndarray] = None):
         """Synchronous: returns (counts int32[nrows,ncols] | None, bytes uint8[nrows,ncols] | None, TileStats)."""
         cv = self._cview(view, window)
         shape = (cv.nrows, cv.ncols)
-        flags = L.KERNELS[kernel]
+        flags = L.KERNELS[kernel] | L.PRECISIONS[precision]
         counts = byts = None
         if want_counts:
             counts = out_counts if out_counts is not None else np.empty(shape, np.int32)
@@ -167,6 +167,25 @@ class MandelbrotDevice:
             counts.ctypes.data if counts is not None else None, C.byref(st)))
         return byts, counts, _stats(st)
 
+    def compute_view_smooth(self, view: View, mrd: int, *, window=None, kernel: str = "default"):
+        """BASELINE cfg5 (not in the reference): continuous escape-time value nu = n + 1 - log2(0.5 ln|z_n|^2)
+        at the reference's bailout, 0 for never-escaped pixels.
+        Returns (smooth float64[nrows,ncols], counts int32[nrows,ncols], TileStats)."""
+        cv = self._cview(view, window)
+        shape = (cv.nrows, cv.ncols)
+        smooth = np.empty(shape, np.float64)
+        counts = np.empty(shape, np.int32)
+        st = L.mbk_stats()
+        self._check(self._lib.mbk_view_compute_smooth(self._h, C.byref(cv), mrd, L.KERNELS[kernel],
+                                                      counts.ctypes.data, smooth.ctypes.data, C.byref(st)))
+        return smooth, counts, _stats(st)
+
+    def launch_view_smooth(self, view: View, mrd: int, *, d_smooth: int, d_counts: int = 0, stream: int = 0,
+                           window=None, kernel: str = "default") -> None:
+        cv = self._cview(view, window)
+        self._check(self._lib.mbk_view_launch_smooth(self._h, C.byref(cv), mrd, L.KERNELS[kernel],
+                                                     d_counts or None, d_smooth, stream or None))
+
     def serialize_last(self) -> Tuple[bytes, int]:
         """The last tile's quantised bytes exactly as DataChunk.Serialize (DataChunk.cs:173-206) would
         write them (code byte + Raw or RLE payload, the shorter; Raw on ties), encoded on the GPU.
@@ -184,11 +203,12 @@ class MandelbrotDevice:
         return self._ser_buf[:size.value].tobytes(), int(codec.value)
 
     def launch_view(self, view: View, mrd: int, *, d_counts: int = 0, d_bytes: int = 0,
-                    stream: int = 0, window=None, kernel: str = "default") -> None:
+                    stream: int = 0, window=None, kernel: str = "default", precision: str = "f64") -> None:
         """Asynchronous launch on raw DEVICE pointers (e.g. torch tensors' data_ptr()) on ``stream``
         (a hipStream_t as int; 0 = HIP's null stream, which is also torch's default stream)."""
         cv = self._cview(view, window)
-        flags = L.KERNELS[kernel] | (L.MBK_WANT_COUNTS if d_counts else 0) | (L.MBK_WANT_BYTES if d_bytes else 0)
+        flags = (L.KERNELS[kernel] | L.PRECISIONS[precision] | (L.MBK_WANT_COUNTS if d_counts else 0)
+                 | (L.MBK_WANT_BYTES if d_bytes else 0))
         self._check(self._lib.mbk_view_launch(self._h, C.byref(cv), mrd, flags,
                                               d_counts or None, d_bytes or None, stream or None))
 

@@ -52,21 +52,32 @@ Workload = Tuple[int, int, int, int]  # (level, mrd, indexReal, indexImag)
 ComputeFn = Callable[[int, int, int, int], np.ndarray]
 
 _default_device = None
+_default_pinned = None
 _default_lock = threading.Lock()
 
 
 def _get_default_device():
-    global _default_device
+    global _default_device, _default_pinned
     with _default_lock:
         if _default_device is None:
             from .device import MandelbrotDevice  # raises if the HIP library / GPU is missing
             _default_device = MandelbrotDevice(0)
+            _default_pinned = _default_device.pinned_empty((CHUNK_BYTES,), np.uint8)
         return _default_device
 
 
 def process_workload(level: int, mrd: int, index_real: int, index_imag: int) -> np.ndarray:
-    """WorkerCUDA.py:70-100 on the default GPU: the tile's 16 777 216 quantised bytes."""
+    """WorkerCUDA.py:70-100 on the default GPU: the tile's 16 777 216 quantised bytes (a fresh array,
+    like the reference's)."""
     out, _, _ = _get_default_device().datachunk(level, mrd, index_real, index_imag)
+    return out
+
+
+def _process_workload_pinned(level: int, mrd: int, index_real: int, index_imag: int) -> np.ndarray:
+    """Same tile, but DMA'd straight into one reused pinned buffer (valid until the next call): what
+    do_workload_single uses, since it sends the bytes before asking for the next tile."""
+    dev = _get_default_device()
+    out, _, _ = dev.datachunk(level, mrd, index_real, index_imag, out_bytes=_default_pinned)
     return out
 
 
@@ -140,7 +151,7 @@ def do_workload_single(addr: str, port: int, compute: Optional[ComputeFn] = None
     log("Workload received:", workload)
     log("Starting calculation...")
     t0 = time.perf_counter()
-    out = (compute or process_workload)(*workload)
+    out = (compute or _process_workload_pinned)(*workload)
     log("Calculation complete (%.1f ms)" % ((time.perf_counter() - t0) * 1e3))
     if submit_workload(addr, port, workload, out):
         log("Response accepted")

@@ -54,6 +54,13 @@ enum mbk_status {
 #define MBK_KERNEL_REFILL 0x300u /* persistent waves with lane refill (deep-zoom divergence) */
 #define MBK_KERNEL_GROUP 0x400u  /* hand-scheduled loop, bailout tested once per 4 steps + exact replay */
 
+/* Arithmetic of the escape loop (bit 12).  Default = IEEE binary64, the reference's arithmetic.
+ * MBK_PRECISION_F32 is BASELINE config 4's "fp32 kernel variant" -- NOT in the reference (its only
+ * signature is int32(float64, float64, int32), WorkerCUDA.py:39): coordinates are generated in fp64
+ * exactly as above, rounded once to binary32, and the loop runs in strict (contraction-free) binary32.
+ * Its oracle is oracle/mandel_oracle.c:mbo_escape_f32.  Supported by the asm / group kernels. */
+#define MBK_PRECISION_F32 0x1000u
+
 typedef struct mbk_ctx mbk_ctx;
 
 /*
@@ -142,6 +149,20 @@ int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t 
  * h_counts: optional int32[16777216] (NULL to skip its D2H). */
 int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_real,
                   uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, mbk_stats *stats);
+
+/*
+ * BASELINE config 5 -- continuous ("smooth") escape-time colouring.  NOT in the reference (its output
+ * is the integer index quantised to a byte, WorkerCUDA.py:96-98); defined here as
+ *     nu = n + 1 - log2(0.5 * ln |z_n|^2)   for a pixel that escapes at step n (|z_n|^2 >= 4 is the
+ *                                            reference's own bailout value), and 0 if it never escapes,
+ * in binary64.  n is the bit-exact count of the parity kernels (also returned); the logarithms are the
+ * device's (tests allow 1e-12 against libm).  Asynchronous form on DEVICE pointers / caller's stream,
+ * and synchronous form into HOST buffers.  d_counts / h_counts may be NULL.
+ */
+int mbk_view_launch_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                           int32_t *d_counts, double *d_smooth, void *hip_stream);
+int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                            int32_t *h_counts, double *h_smooth, mbk_stats *stats);
 
 /* Codec codes of DataChunkSerializer.cs (Raw :20, RLE :54). */
 #define MBK_CODEC_RAW 0x00u

@@ -96,6 +96,74 @@ int32_t mbo_escape(double cr, double ci, int32_t mrd)
     return 0;
 }
 
+/* BASELINE config 4's fp32 variant (NOT in the reference; parity unpinned by it -- this function IS its
+ * definition): the same loop in strict binary32.  The coordinates are the fp64 np.linspace values
+ * rounded once to float. */
+int32_t mbo_escape_f32(float cr, float ci, int32_t mrd)
+{
+    float zr = cr, zi = ci;
+    for (int32_t n = 1; n < mrd; ++n) {
+        float a = zr * zr;
+        float b = zi * zi;
+        float t = a - b;
+        float w = 2.0f * zr;
+        float u = w * zi;
+        zr = t + cr;
+        zi = u + ci;
+        float m0 = zr * zr;
+        float m1 = zi * zi;
+        float m = m0 + m1;
+        if (m >= 4.0f) return n;
+    }
+    return 0;
+}
+
+/* BASELINE config 5 (NOT in the reference): continuous escape-time value at the reference's bailout.
+ * Runs the reference loop, keeps |z|^2 of the escaping step, nu = n + 1 - log2(0.5 * ln |z_n|^2); 0 if the
+ * pixel never escapes.  *count_out receives the integer escape index. */
+double mbo_escape_smooth(double cr, double ci, int32_t mrd, int32_t *count_out)
+{
+    double zr = cr, zi = ci;
+    for (int32_t n = 1; n < mrd; ++n) {
+        double a = zr * zr;
+        double b = zi * zi;
+        double t = a - b;
+        double w = 2.0 * zr;
+        double u = w * zi;
+        zr = t + cr;
+        zi = u + ci;
+        double m0 = zr * zr;
+        double m1 = zi * zi;
+        double m = m0 + m1;
+        if (m >= 4.0) {
+            if (count_out) *count_out = n;
+            return (double)n + 1.0 - log2(0.5 * log(m));
+        }
+    }
+    if (count_out) *count_out = 0;
+    return 0.0;
+}
+
+void mbo_view_smooth(double start_r, double start_i, double range_r, double range_i,
+                     uint32_t width, uint32_t height, int32_t mrd, double *smooth, int32_t *counts)
+{
+    double *xr = (double *)malloc(sizeof(double) * (width ? width : 1));
+    double *xi = (double *)malloc(sizeof(double) * (height ? height : 1));
+    mbo_axis(start_r, range_r, width, xr);
+    mbo_axis(start_i, range_i, height, xi);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+    for (int64_t r = 0; r < (int64_t)height; ++r)
+        for (uint32_t c = 0; c < width; ++c) {
+            int32_t cnt;
+            smooth[(size_t)r * width + c] = mbo_escape_smooth(xr[c], xi[r], mrd, &cnt);
+            if (counts) counts[(size_t)r * width + c] = cnt;
+        }
+    free(xr);
+    free(xi);
+}
+
 /* WorkerCUDA.py:96-98: out = (out.astype(float64) * 256) / mrd; ceil(out).astype(uint8).
  * 256.0 wraps to 0 (numpy's C cast on x86-64).  mrd == 0 would be 0/0 = NaN -> 0. */
 uint8_t mbo_quantise(int32_t count, uint32_t mrd)
@@ -113,10 +181,10 @@ uint8_t mbo_quantise(int32_t count, uint32_t mrd)
  * imaginary the slow one (np.repeat, :35).  Either output pointer may be NULL.
  * Returns the number of pixel-iterations executed (count if count>0 else max(mrd-1,0)).
  */
-uint64_t mbo_view(double start_r, double start_i, double range_r, double range_i,
-                  uint32_t width, uint32_t height,
-                  uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
-                  int32_t mrd, int32_t *counts, uint8_t *bytes, int nthreads)
+static uint64_t mbo_view_impl(double start_r, double start_i, double range_r, double range_i,
+                              uint32_t width, uint32_t height,
+                              uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
+                              int32_t mrd, int32_t *counts, uint8_t *bytes, int nthreads, int f32)
 {
     double *xr = (double *)malloc(sizeof(double) * (width ? width : 1));
     double *xi = (double *)malloc(sizeof(double) * (height ? height : 1));
@@ -134,7 +202,8 @@ uint64_t mbo_view(double start_r, double start_i, double range_r, double range_i
         double ci = xi[row0 + r];
         uint64_t acc = 0;
         for (uint32_t c = 0; c < ncols; ++c) {
-            int32_t cnt = mbo_escape(xr[col0 + c], ci, mrd);
+            int32_t cnt = f32 ? mbo_escape_f32((float)xr[col0 + c], (float)ci, mrd)
+                              : mbo_escape(xr[col0 + c], ci, mrd);
             size_t o = (size_t)r * ncols + c;
             if (counts) counts[o] = cnt;
             if (bytes) bytes[o] = mbo_quantise(cnt, (uint32_t)mrd);
@@ -145,6 +214,24 @@ uint64_t mbo_view(double start_r, double start_i, double range_r, double range_i
     free(xr);
     free(xi);
     return total;
+}
+
+uint64_t mbo_view(double start_r, double start_i, double range_r, double range_i,
+                  uint32_t width, uint32_t height,
+                  uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
+                  int32_t mrd, int32_t *counts, uint8_t *bytes, int nthreads)
+{
+    return mbo_view_impl(start_r, start_i, range_r, range_i, width, height, col0, row0, ncols, nrows, mrd,
+                         counts, bytes, nthreads, 0);
+}
+
+uint64_t mbo_view_f32(double start_r, double start_i, double range_r, double range_i,
+                      uint32_t width, uint32_t height,
+                      uint32_t col0, uint32_t row0, uint32_t ncols, uint32_t nrows,
+                      int32_t mrd, int32_t *counts, uint8_t *bytes, int nthreads)
+{
+    return mbo_view_impl(start_r, start_i, range_r, range_i, width, height, col0, row0, ncols, nrows, mrd,
+                         counts, bytes, nthreads, 1);
 }
 
 /* process_workload, WorkerCUDA.py:70-100: one 4096 x 4096 DataChunk tile. */

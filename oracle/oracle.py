@@ -49,6 +49,13 @@ class COracle:
                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32,
                                C.c_void_p, C.c_void_p, C.c_int]
         L.mbo_view.restype = C.c_uint64
+        L.mbo_view_f32.argtypes = L.mbo_view.argtypes
+        L.mbo_view_f32.restype = C.c_uint64
+        L.mbo_escape_f32.argtypes = [C.c_float, C.c_float, C.c_int32]
+        L.mbo_escape_f32.restype = C.c_int32
+        L.mbo_view_smooth.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
+                                      C.c_int32, C.c_void_p, C.c_void_p]
+        L.mbo_view_smooth.restype = None
         L.mbo_datachunk.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_int]
         L.mbo_datachunk.restype = C.c_uint64
@@ -74,16 +81,25 @@ class COracle:
         return int(self.lib.mbo_quantise(count, mrd))
 
     def view(self, start_r, start_i, range_r, range_i, width, height, mrd, *, window=None,
-             want_counts=True, want_bytes=True, nthreads=0):
+             want_counts=True, want_bytes=True, nthreads=0, precision="f64"):
         """Returns (counts int32[nrows,ncols] | None, bytes uint8[nrows,ncols] | None, pixel_iters)."""
         col0, row0, ncols, nrows = window if window is not None else (0, 0, width, height)
         counts = np.empty((nrows, ncols), dtype=np.int32) if want_counts else None
         byts = np.empty((nrows, ncols), dtype=np.uint8) if want_bytes else None
-        total = self.lib.mbo_view(start_r, start_i, range_r, range_i, width, height,
+        fn = self.lib.mbo_view_f32 if precision == "f32" else self.lib.mbo_view
+        total = fn(start_r, start_i, range_r, range_i, width, height,
                                   col0, row0, ncols, nrows, mrd,
                                   counts.ctypes.data if want_counts else None,
                                   byts.ctypes.data if want_bytes else None, nthreads)
         return counts, byts, int(total)
+
+    def view_smooth(self, start_r, start_i, range_r, range_i, width, height, mrd):
+        """(smooth float64[h,w], counts int32[h,w]) -- BASELINE cfg5, see mbo_escape_smooth."""
+        smooth = np.empty((height, width), np.float64)
+        counts = np.empty((height, width), np.int32)
+        self.lib.mbo_view_smooth(start_r, start_i, range_r, range_i, width, height, mrd,
+                                 smooth.ctypes.data, counts.ctypes.data)
+        return smooth, counts
 
     def datachunk(self, level, mrd, index_real, index_imag, *, want_counts=True, nthreads=0):
         counts = np.empty((4096, 4096), dtype=np.int32) if want_counts else None
@@ -109,9 +125,10 @@ def numpy_axis(start: float, rng: float, n: int) -> np.ndarray:
     return np.linspace(start=start, stop=start + rng, num=n)
 
 
-def numpy_escape(cr: np.ndarray, ci: np.ndarray, mrd: int) -> np.ndarray:
-    """WorkerCUDA.py:39-68, vectorised with an 'alive' mask.  Arrays broadcast."""
-    cr, ci = np.broadcast_arrays(np.asarray(cr, np.float64), np.asarray(ci, np.float64))
+def numpy_escape(cr: np.ndarray, ci: np.ndarray, mrd: int, dtype=np.float64) -> np.ndarray:
+    """WorkerCUDA.py:39-68, vectorised with an 'alive' mask.  Arrays broadcast.  dtype=np.float32 gives
+    the strict-binary32 variant (inputs are rounded to float32 first; numpy keeps float32 arithmetic)."""
+    cr, ci = np.broadcast_arrays(np.asarray(cr, np.float64).astype(dtype), np.asarray(ci, np.float64).astype(dtype))
     cr = np.ascontiguousarray(cr).ravel()
     ci = np.ascontiguousarray(ci).ravel()
     out = np.zeros(cr.shape, np.int32)
@@ -122,11 +139,11 @@ def numpy_escape(cr: np.ndarray, ci: np.ndarray, mrd: int) -> np.ndarray:
             if idx.size == 0:
                 break
             t = zr * zr - zi * zi
-            u = (2 * zr) * zi
+            u = (dtype(2) * zr) * zi
             zr = t + kr
             zi = u + ki
             m = zr * zr + zi * zi
-            esc = m >= 4
+            esc = m >= dtype(4)
             if esc.any():
                 out[idx[esc]] = n
                 keep = ~esc

@@ -194,3 +194,48 @@ def test_render_view_multi_queue_single_gpu(gpu, oracle):
     oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, 640, 500, mrd)
     assert np.array_equal(c, oc) and np.array_equal(b, ob)
     assert per[0]["bands"] == 8 and per[0]["pixel_iterations"] == total
+
+
+@pytest.mark.parametrize("kernel", ["default", "asm", "group"])
+def test_f32_variant_against_f32_oracle(gpu, oracle, kernel):
+    """BASELINE cfg4 (fp32 kernel variant): bit-exact against the strict-binary32 oracle."""
+    rs = np.random.RandomState(4)
+    cases = [
+        (View(-2.0, -1.5, 3.0, 3.0, 512, 384), 256),
+        (View(-0.755, 0.10, 0.02, 0.02, 256, 256), 50000),     # cfg4's region and mrd, small window
+        (View(-2.0, -2.0, 4.0, 4.0, 130, 70), 300),             # crosses the |c| = 2 ring (per-step path)
+        (View(-0.75, -1e-40, 0.5, 2e-40, 64, 8), 500),         # tiny imaginary parts -> exact doubling
+        (View(1.0e3, 1.0e3, 1.0, 1.0, 9, 9), 50),
+    ]
+    for _ in range(4):
+        cr, ci = rs.uniform(-1.6, 0.4), rs.uniform(-1.1, 1.1)
+        span = 10.0 ** rs.uniform(-4, 0)
+        cases.append((View(cr, ci, span, span, int(rs.randint(1, 300)), int(rs.randint(1, 300))), int(rs.randint(2, 1500))))
+    for view, mrd in cases:
+        c, b, st = gpu.compute_view(view, mrd, kernel=kernel, precision="f32")
+        oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width,
+                                    view.height, mrd, precision="f32")
+        assert np.array_equal(c, oc), (view, mrd, kernel, int((c != oc).sum()))
+        assert np.array_equal(b, ob) and st.pixel_iterations == total
+    from distributedmandelbrot_amd import MbkError
+    with pytest.raises(MbkError):
+        gpu.compute_view(View(-2.0, -1.5, 3.0, 3.0, 16, 16), 10, kernel="simple", precision="f32")
+    with pytest.raises(MbkError):
+        gpu.compute_view(View(1e30, 0.0, 1.0, 1.0, 4, 4), 10, precision="f32")   # beyond the fp32 domain
+
+
+@pytest.mark.parametrize("kernel", ["default", "asm", "group"])
+def test_smooth_colouring_cfg5(gpu, oracle, kernel):
+    """BASELINE cfg5: integer part (the count) bit-exact, the continuous value within 1e-12 of the libm
+    evaluation of the same formula on the same |z_n|^2."""
+    cases = [(View(-2.0, -1.5, 3.0, 3.0, 512, 512), 5000), (View(-0.755, 0.10, 0.02, 0.02, 300, 200), 5000),
+             (View(-2.0, -2.0, 4.0, 4.0, 65, 33), 40), (View(-0.1, -0.1, 0.2, 0.2, 16, 16), 100)]
+    for view, mrd in cases:
+        sm, c, st = gpu.compute_view_smooth(view, mrd, kernel=kernel)
+        osm, oc = oracle.view_smooth(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd)
+        assert np.array_equal(c, oc)
+        esc = oc > 0
+        assert (sm[~esc] == 0.0).all()
+        assert np.allclose(sm[esc], osm[esc], rtol=0, atol=1e-12 * max(1, mrd)), float(np.abs(sm[esc] - osm[esc]).max())
+        # nu lies in (n, n + 1 - log2(0.5 ln 4)] because |z_n|^2 >= 4
+        assert (sm[esc] <= oc[esc] + 1.0 - np.log2(0.5 * np.log(4.0)) + 1e-12).all()

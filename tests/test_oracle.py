@@ -129,3 +129,34 @@ def test_numpy_escape_matches_scalar(oracle):
     ci = rs.uniform(-1.2, 1.2, 300)
     v = numpy_escape(cr, ci, 400)
     assert [oracle.escape(a, b, 400) for a, b in zip(cr, ci)] == v.tolist()
+
+
+def test_f32_variant_c_oracle_matches_numpy_float32(oracle):
+    """BASELINE cfg4's fp32 variant is not in the reference; its definition is the strict-binary32
+    restatement.  The C and numpy versions must agree bit-for-bit before either judges the GPU."""
+    rs = np.random.RandomState(44)
+    cases = [(-2.0, -1.5, 3.0, 3.0, 120, 90, 300), (-0.755, 0.10, 0.02, 0.02, 64, 64, 2000)]
+    for _ in range(4):
+        cr, ci = rs.uniform(-1.6, 0.4), rs.uniform(-1.1, 1.1)
+        span = 10.0 ** rs.uniform(-4, 0)
+        cases.append((cr, ci, span, span, int(rs.randint(1, 80)), int(rs.randint(1, 80)), int(rs.randint(2, 900))))
+    for sr, si, rr, ri, w, h, mrd in cases:
+        c, b, total = oracle.view(sr, si, rr, ri, w, h, mrd, precision="f32")
+        xr, xi = numpy_axis(sr, rr, w), numpy_axis(si, ri, h)
+        c2 = numpy_escape(xr[None, :], xi[:, None], mrd, dtype=np.float32).reshape(h, w)
+        assert np.array_equal(c, c2)
+        assert np.array_equal(b, numpy_quantise(c2, mrd)) and total == pixel_iterations(c, mrd)
+    assert oracle.lib.mbo_escape_f32(-2.0, 0.0, 100) == 1 and oracle.lib.mbo_escape_f32(0.0, 0.0, 100) == 0
+
+
+def test_smooth_oracle_consistency(oracle):
+    """cfg5 oracle: integer part equals the parity count; value matches a numpy evaluation of the formula."""
+    sm, c = oracle.view_smooth(-2.0, -1.5, 3.0, 3.0, 96, 64, 500)
+    c0, _, _ = oracle.view(-2.0, -1.5, 3.0, 3.0, 96, 64, 500, want_bytes=False)
+    assert np.array_equal(c, c0)
+    assert (sm[c == 0] == 0).all() and (sm[c > 0] > c[c > 0]).all()
+    # c = 2+2i escapes at n=1 with z1 = (2+2i)^2 + (2+2i) = 2 + 10i -> |z|^2 = 104
+    v = oracle.lib.mbo_escape_smooth
+    import ctypes as C
+    v.restype = C.c_double; v.argtypes = [C.c_double, C.c_double, C.c_int32, C.c_void_p]
+    assert abs(v(2.0, 2.0, 10, None) - (2.0 - np.log2(0.5 * np.log(104.0)))) < 1e-15
