@@ -43,7 +43,7 @@ struct mbk_ctx {
     uint8_t *d_rle = nullptr;        // RLE scratch: block counts | run starts | run values | output stream
     size_t rle_cap_px = 0;
     unsigned queue_turn = 0;
-    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32, group_steps = 8;  // tunables (MBK_* env)
+    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32, group_steps = 8, rf_grouped = 1;  // tunables (MBK_* env)
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -254,9 +254,11 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
             if (waves > nblocks) waves = nblocks;
             const dim3 grid((waves + 3u) / 4u), block(256);
             if (safe)
-                hipLaunchKernelGGL(mbk::tile_refill_kernel<false>, grid, block, 0, stream, a, wq);
+                hipLaunchKernelGGL((mbk::tile_refill_kernel<false, false>), grid, block, 0, stream, a, wq);
+            else if (ctx->rf_grouped)
+                hipLaunchKernelGGL((mbk::tile_refill_kernel<true, true>), grid, block, 0, stream, a, wq);
             else
-                hipLaunchKernelGGL(mbk::tile_refill_kernel<true>, grid, block, 0, stream, a, wq);
+                hipLaunchKernelGGL((mbk::tile_refill_kernel<true, false>), grid, block, 0, stream, a, wq);
             break;
         }
         case MBK_KERNEL_SIMPLE: {
@@ -350,6 +352,7 @@ int mbk_create(int device, mbk_ctx **out)
     if (const char *e = std::getenv("MBK_RF_LIVEMIN")) ctx->rf_livemin = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_RF_PATIENCE")) ctx->rf_patience = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_WPW")) { unsigned w = (unsigned)std::atoi(e); if (w == 1 || w == 2 || w == 4) ctx->waves_per_wg = w; }
+    if (const char *e = std::getenv("MBK_RF_GROUPED")) ctx->rf_grouped = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_GROUP")) ctx->group_steps = (unsigned)std::atoi(e) == 4 ? 4u : 8u;
     if (const char *e = std::getenv("MBK_PROBE")) ctx->probe_steps = (unsigned)std::atoi(e) > 1 ? (unsigned)std::atoi(e) : 2u;
     if (const char *e = std::getenv("MBK_LDS")) ctx->lds_pad = (unsigned)std::atoi(e);

@@ -162,7 +162,86 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     "s_mov_b64 %[live], exec\n"                            \
     "s_mov_b64 exec, %[save]\n"
 
-template <bool kFmaDouble>
+// ---- grouped hot loop for the persistent kernel -------------------------------------------------
+// Same idea as escape_steps_group (mbk_loops.inc): 8 unchecked steps on a scratch register set, one
+// NaN-inclusive test per group, exact replay for the lanes that tripped it (cnt = clock - start),
+// two register sets A/B alternating so a group's start state survives until its test.  One trip =
+// 16 steps.  The slow-path exits (too few live lanes / alarm) happen after a replay or at the end of
+// a trip; if the wave leaves after the first group the live state is copied back from set B to set A,
+// which is where the C++ side keeps it.
+#define MBK_RFG_STEP(ZRS, ZIS, AS, BS, ZRD, ZID, AD, BD)   \
+    "v_add_f64 %[t], " AS ", -" BS "\n"                    \
+    "v_mul_f64 %[p], " ZRS ", " ZIS "\n"                   \
+    "v_add_f64 " ZRD ", %[t], %[cr]\n"                     \
+    "v_fma_f64 " ZID ", %[p], 2.0, %[ci]\n"                \
+    "v_mul_f64 " AD ", " ZRD ", " ZRD "\n"                 \
+    "v_mul_f64 " BD ", " ZID ", " ZID "\n"
+#define MBK_RFG_A2T MBK_RFG_STEP("%[zr]", "%[zi]", "%[a]", "%[b]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
+#define MBK_RFG_B2T MBK_RFG_STEP("%[zr2]", "%[zi2]", "%[a2]", "%[b2]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
+#define MBK_RFG_T2T MBK_RFG_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zrt]", "%[zit]", "%[at]", "%[bt]")
+#define MBK_RFG_T2A MBK_RFG_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zr]", "%[zi]", "%[a]", "%[b]")
+#define MBK_RFG_T2B MBK_RFG_STEP("%[zrt]", "%[zit]", "%[at]", "%[bt]", "%[zr2]", "%[zi2]", "%[a2]", "%[b2]")
+#define MBK_RFG_GROUP8(FIRST, LAST, AD, BD, ID)            \
+    FIRST MBK_RFG_T2T MBK_RFG_T2T MBK_RFG_T2T MBK_RFG_T2T MBK_RFG_T2T MBK_RFG_T2T LAST \
+    "v_add_f64 %[m], " AD ", " BD "\n"                     \
+    "v_cmp_ngt_f64 vcc, 4.0, %[m]\n"                       \
+    "s_cbranch_vccnz .Lqrep" ID "_%=\n"                    \
+    ".Lqcont" ID "_%=:\n"
+#define MBK_RFG_REPLAY_STEP(STEP, J)                       \
+    STEP                                                   \
+    "v_add_f64 %[m], %[at], %[bt]\n"                       \
+    "v_cmp_le_f64 vcc, 4.0, %[m]\n"                        \
+    "s_add_u32 %[k], %[n], " J "\n"                        \
+    "s_or_b64 %[esc], %[esc], vcc\n"                       \
+    "s_and_saveexec_b64 %[tmp2], vcc\n"                    \
+    "v_sub_u32 %[cnt], %[k], %[start]\n"                   \
+    "s_andn2_b64 exec, %[tmp2], vcc\n"
+#define MBK_RFG_REPLAY8(FIRST, ID, J1, J2, J3, J4, J5, J6, J7, J8, NADV, COPYBACK) \
+    ".Lqrep" ID "_%=:\n"                                   \
+    "s_and_saveexec_b64 %[tmp], vcc\n"                     \
+    "s_mov_b64 %[esc], 0\n"                                \
+    MBK_RFG_REPLAY_STEP(FIRST, J1) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J2) \
+    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J3) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J4) \
+    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J5) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J6) \
+    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J7) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J8) \
+    "s_andn2_b64 exec, %[tmp], %[esc]\n"                   \
+    "s_cbranch_scc0 .Lqexit" ID "_%=\n"                    \
+    "s_bcnt1_i32_b64 %[k2], exec\n"                        \
+    "s_cmp_le_u32 %[k2], %[livemin]\n"                     \
+    "s_cbranch_scc1 .Lqexit" ID "_%=\n"                    \
+    "s_add_u32 %[k2], %[n], " NADV "\n"                    \
+    "s_add_u32 %[k2], %[k2], %[patience]\n"                \
+    "s_sub_u32 %[k3], %[k2], %[alarm]\n"                   \
+    "s_cmp_lt_i32 %[k3], 0\n"                              \
+    "s_cselect_b32 %[alarm], %[k2], %[alarm]\n"            \
+    "s_branch .Lqcont" ID "_%=\n"                          \
+    ".Lqexit" ID "_%=:\n"                                  \
+    COPYBACK                                               \
+    "s_add_u32 %[n], %[n], " NADV "\n"                     \
+    "s_branch .Lqout_%=\n"
+#define MBK_RFG_COPY_B2A                                   \
+    "v_mov_b64 %[zr], %[zr2]\n"                            \
+    "v_mov_b64 %[zi], %[zi2]\n"                            \
+    "v_mov_b64 %[a], %[a2]\n"                              \
+    "v_mov_b64 %[b], %[b2]\n"
+#define MBK_RFG_LOOP                                       \
+    "s_mov_b64 %[save], exec\n"                            \
+    "s_mov_b64 exec, %[live]\n"                            \
+    ".Lqmain_%=:\n"                                        \
+    MBK_RFG_GROUP8(MBK_RFG_A2T, MBK_RFG_T2B, "%[a2]", "%[b2]", "1") \
+    MBK_RFG_GROUP8(MBK_RFG_B2T, MBK_RFG_T2A, "%[a]", "%[b]", "2")   \
+    "s_add_u32 %[n], %[n], 16\n"                           \
+    "s_sub_u32 %[k3], %[n], %[alarm]\n"                    \
+    "s_cmp_lt_i32 %[k3], 0\n"                              \
+    "s_cbranch_scc1 .Lqmain_%=\n"                          \
+    "s_branch .Lqout_%=\n"                                 \
+    MBK_RFG_REPLAY8(MBK_RFG_A2T, "1", "1", "2", "3", "4", "5", "6", "7", "8", "8", MBK_RFG_COPY_B2A)   \
+    MBK_RFG_REPLAY8(MBK_RFG_B2T, "2", "9", "10", "11", "12", "13", "14", "15", "16", "16", "")         \
+    ".Lqout_%=:\n"                                         \
+    "s_mov_b64 %[live], exec\n"                            \
+    "s_mov_b64 exec, %[save]\n"
+
+template <bool kFmaDouble, bool kGrouped = false>
 __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues *wq)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -173,6 +252,7 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
 
     double cr = 0.0, ci = 0.0, zr = 0.0, zi = 0.0, a = 0.0, b = 0.0;
     uint32_t start = 0, cnt = 0, opix = 0;
+    bool risky = false;           // | |c|^2 - 4 | < 1e-9: the grouped test may not be used while such a pixel is live
     unsigned long long live = 0;  // wave-uniform: lanes with a pixel in flight
     uint32_t n = 0;               // wave-uniform clock: steps executed by this wave so far
     uint32_t bound = 0;           // lower bound on the earliest clock at which a live lane hits mrd-1
@@ -245,6 +325,8 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
                     start = n;
                     cnt = 0;
                     opix = lr * p.ncols + lc;
+                    const double c2 = a + b;
+                    risky = c2 > 4.0 - 1e-9 && c2 < 4.0 + 1e-9;
                     valid = true;
                 }
             }
@@ -271,7 +353,22 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
             const uint32_t patience = uniform_u32(more ? p.rf_patience : kFar);   // ... or 32 steps after an escape
             n = uniform_u32(n);
             live = uniform_u64(live);
-            if (kFmaDouble) {
+            const bool any_risky = __ballot(risky && ((live >> lane) & 1ull)) != 0;
+            if (kGrouped && kFmaDouble && !any_risky) {
+                double zr2, zi2, a2, b2, zrt, zit, at, bt;
+                unsigned long long tmp2, esc;
+                asm volatile(MBK_RFG_LOOP
+                             : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b),
+                               [cnt] "+&v"(cnt), [zr2] "=&v"(zr2), [zi2] "=&v"(zi2), [a2] "=&v"(a2),
+                               [b2] "=&v"(b2), [zrt] "=&v"(zrt), [zit] "=&v"(zit), [at] "=&v"(at),
+                               [bt] "=&v"(bt), [t] "=&v"(t), [p] "=&v"(pr), [m] "=&v"(m),
+                               [n] "+&s"(n), [live] "+&s"(live), [alarm] "+&s"(alarm),
+                               [k] "=&s"(k), [k2] "=&s"(k2), [k3] "=&s"(k3), [save] "=&s"(save),
+                               [tmp] "=&s"(tmp), [tmp2] "=&s"(tmp2), [esc] "=&s"(esc)
+                             : [cr] "v"(cr), [ci] "v"(ci), [start] "v"(start), [livemin] "s"(livemin),
+                               [patience] "s"(patience)
+                             : "vcc", "scc");
+            } else if (kFmaDouble) {
                 asm volatile(MBK_RF_LOOP(MBK_RF_HEAD_FMA)
                              : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b),
                                [cnt] "+&v"(cnt), [t] "=&v"(t), [p] "=&v"(pr), [m] "=&v"(m),
