@@ -241,6 +241,18 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     "s_mov_b64 %[live], exec\n"                            \
     "s_mov_b64 exec, %[save]\n"
 
+// per-lane predicate from a wave-uniform mask without 64-bit VALU shifts
+__device__ __forceinline__ bool lane_in(unsigned long long uniform_mask)
+{
+    return __builtin_amdgcn_inverse_ballot_w64(uniform_mask);
+}
+// rank of this lane among the set bits below it
+__device__ __forceinline__ uint32_t rank_in(unsigned long long uniform_mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(uniform_mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)uniform_mask, 0u));
+}
+
 template <bool kFmaDouble, bool kGrouped = false>
 __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues *wq)
 {
@@ -249,49 +261,54 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
     const uint32_t total = (uint32_t)p.mrd - 1u;  // host guarantees mrd >= 2
     const uint32_t bxn = (p.ncols + 7u) / 8u;     // 8x8 blocks per block-row
     constexpr uint32_t kFar = 0x40000000u;         // all relative clock offsets stay below 2^30
+    const bool want_bytes = p.bytes != nullptr;
 
     double cr = 0.0, ci = 0.0, zr = 0.0, zi = 0.0, a = 0.0, b = 0.0;
     uint32_t start = 0, cnt = 0, opix = 0;
-    bool risky = false;           // | |c|^2 - 4 | < 1e-9: the grouped test may not be used while such a pixel is live
+    bool risky = false;           // | |c|^2 - 4 | < 1e-9: no grouped test while such a pixel is live
     unsigned long long live = 0;  // wave-uniform: lanes with a pixel in flight
+    unsigned long long live_in = 0;
     uint32_t n = 0;               // wave-uniform clock: steps executed by this wave so far
     uint32_t bound = 0;           // lower bound on the earliest clock at which a live lane hits mrd-1
-    uint32_t blk = 0, blk_pos = 64, blk_left = 0;  // current block, next pixel in it, blocks still owned
+    // current block (all wave-uniform): pixel origin, next pixel in it, blocks still owned, and whether
+    // the cheap refill path applies (block wholly inside the window, away from both axis end points)
+    uint32_t blk = 0, blk_col = 0, blk_row = 0, blk_pos = 64, blk_left = 0;
+    bool blk_simple = false;
     bool more = true;
     const uint32_t nblocks = bxn * ((p.nrows + 7u) / 8u);
+    const bool axes_simple = !p.re.step_is_zero && !p.im.step_is_zero;
     Popper pp;
     pp.cq = home;
     pp.cq_end = queue_lo(nblocks, home + 1u);
 
-    unsigned long long live_in = 0;
     for (;;) {
-        // ---------------- retire lanes that escaped during this run ---------------------------------
+        // ---------------- retire lanes that escaped during the last run ------------------------------
         const unsigned long long finished = live_in & ~live;
-        if ((finished >> lane) & 1ull) {
+        if (finished != 0 && lane_in(finished)) {
             const int32_t count = cnt <= total ? (int32_t)cnt : 0;  // an escape past mrd-1 is "never"
             if (p.counts) p.counts[opix] = count;
-            if (p.bytes) p.bytes[opix] = quantise(count, p.mrd, p.quant_wide);
+            if (want_bytes) p.bytes[opix] = quantise(count, p.mrd, p.quant_wide);
         }
         live_in = live;
         // ---------------- mrd deadline: lanes that ran mrd-1 steps without escaping -> 0 -------------
         if ((int32_t)(n - bound) >= 0) {
-            const bool is_live = (live >> lane) & 1ull;
+            const bool is_live = lane_in(live);
             const uint32_t age = n - start;
             const bool expired = is_live && age >= total;
             if (expired) {
                 if (p.counts) p.counts[opix] = 0;
-                if (p.bytes) p.bytes[opix] = 0;
+                if (want_bytes) p.bytes[opix] = 0;
             }
             live &= ~__ballot(expired);
             uint32_t rem = (is_live && !expired) ? total - age : kFar;
             rem = wave_min_u32(rem < kFar ? rem : kFar);
-            bound = n + (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);  // uniform by construction
+            bound = n + uniform_u32(rem);
         }
-        // ---------------- refill: free lanes take the next pixels of the wave's current block -----
+        // ---------------- refill ----------------------------------------------------------------------
         const bool was_empty = (live == 0);
         unsigned long long free_lanes = ~live;
         while (more && free_lanes != 0) {
-            if (blk_pos >= 64u) {
+            if (blk_pos >= 64u) {  // need the next block
                 if (blk_left > 0) {
                     ++blk;
                     --blk_left;
@@ -304,17 +321,45 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
                     }
                     blk_left = got - 1u;
                 }
+                const uint32_t by = blk / bxn, bx = blk - by * bxn;  // scalar ALU (uniform)
+                blk_col = bx * 8u;
+                blk_row = by * 8u;
                 blk_pos = 0;
+                blk_simple = axes_simple && blk_col + 8u <= p.ncols && blk_row + 8u <= p.nrows &&
+                             p.col0 + blk_col + 8u < p.re.n && p.row0 + blk_row + 8u < p.im.n;
             }
             const uint32_t navail = 64u - blk_pos;
-            const bool is_free = (free_lanes >> lane) & 1ull;
-            const uint32_t rank = (uint32_t)__popcll(free_lanes & ((1ull << lane) - 1ull));
+            const uint32_t nfree = (uint32_t)__popcll(free_lanes);
+            if (blk_simple && nfree <= navail) {
+                // fast path (the common case): every free lane takes a pixel of this interior block;
+                // coordinates by the two-rounding linspace formula, no end-point / edge handling needed
+                if (lane_in(free_lanes)) {
+                    const uint32_t pidx = blk_pos + rank_in(free_lanes);
+                    const uint32_t lc = blk_col + (pidx & 7u), lr = blk_row + (pidx >> 3);
+                    cr = (double)(p.col0 + lc) * p.re.step + p.re.start;
+                    ci = (double)(p.row0 + lr) * p.im.step + p.im.start;
+                    zr = cr;
+                    zi = ci;
+                    a = zr * zr;
+                    b = zi * zi;
+                    start = n;
+                    cnt = 0;
+                    opix = lr * p.ncols + lc;
+                    const double c2 = a + b;
+                    risky = c2 > 4.0 - 1e-9 && c2 < 4.0 + 1e-9;
+                }
+                live = ~0ull;
+                blk_pos += nfree;
+                break;
+            }
+            // general path: block edges, axis end points, or the block runs out mid-refill
+            const bool is_free = lane_in(free_lanes);
+            const uint32_t rank = rank_in(free_lanes);
             const bool take = is_free && rank < navail;
             bool valid = false;
             if (take) {
                 const uint32_t pidx = blk_pos + rank;
-                const uint32_t by = blk / bxn, bx = blk - by * bxn;
-                const uint32_t lc = bx * 8u + (pidx & 7u), lr = by * 8u + (pidx >> 3);
+                const uint32_t lc = blk_col + (pidx & 7u), lr = blk_row + (pidx >> 3);
                 if (lc < p.ncols && lr < p.nrows) {
                     cr = axis_value(p.re, p.col0 + lc);
                     ci = axis_value(p.im, p.row0 + lr);
@@ -349,11 +394,11 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
             unsigned long long save, tmp;
             // all of these are wave-uniform by construction; say so to the register allocator
             uint32_t alarm = uniform_u32(bound);
-            const uint32_t livemin = uniform_u32(more ? p.rf_livemin : 0u);     // refill once >= 16 lanes are free
-            const uint32_t patience = uniform_u32(more ? p.rf_patience : kFar);   // ... or 32 steps after an escape
+            const uint32_t livemin = uniform_u32(more ? p.rf_livemin : 0u);     // refill once enough lanes are free
+            const uint32_t patience = uniform_u32(more ? p.rf_patience : kFar);   // ... or this long after an escape
             n = uniform_u32(n);
             live = uniform_u64(live);
-            const bool any_risky = __ballot(risky && ((live >> lane) & 1ull)) != 0;
+            const bool any_risky = __ballot(risky && lane_in(live)) != 0;
             if (kGrouped && kFmaDouble && !any_risky) {
                 double zr2, zi2, a2, b2, zrt, zit, at, bt;
                 unsigned long long tmp2, esc;
@@ -390,7 +435,6 @@ __global__ __launch_bounds__(256) void tile_refill_kernel(TileArgs p, WorkQueues
                              : "vcc", "scc");
             }
         }
-
     }
 }
 

@@ -239,3 +239,36 @@ def test_smooth_colouring_cfg5(gpu, oracle, kernel):
         assert np.allclose(sm[esc], osm[esc], rtol=0, atol=1e-12 * max(1, mrd)), float(np.abs(sm[esc] - osm[esc]).max())
         # nu lies in (n, n + 1 - log2(0.5 ln 4)] because |z_n|^2 >= 4
         assert (sm[esc] <= oc[esc] + 1.0 - np.log2(0.5 * np.log(4.0)) + 1e-12).all()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_fuzz_many_small_views(gpu, oracle, precision):
+    """120 seeded random small views (random centre incl. the |c| = 2 ring and the set boundary, random
+    aspect, window and mrd): default kernel bit-exact against the oracle of the same precision."""
+    rs = np.random.RandomState(77 if precision == "f64" else 78)
+    for k in range(120):
+        kind = k % 4
+        if kind == 0:      # anywhere in the reference's domain [-2,2]^2
+            cr, ci = rs.uniform(-2, 2), rs.uniform(-2, 2)
+        elif kind == 1:    # on the |c| = 2 circle (grouped test must fall back to per-step)
+            th = rs.uniform(0, 2 * np.pi)
+            cr, ci = 2 * np.cos(th), 2 * np.sin(th)
+        elif kind == 2:    # near the boundary of the main cardioid
+            th = rs.uniform(0, 2 * np.pi)
+            cr, ci = 0.5 * np.cos(th) - 0.25 * np.cos(2 * th), 0.5 * np.sin(th) - 0.25 * np.sin(2 * th)
+        else:              # real axis / antenna
+            cr, ci = rs.uniform(-2, 0.3), 0.0
+        span_r = 10.0 ** rs.uniform(-9, 0.3)
+        span_i = span_r * rs.uniform(0.3, 3.0)
+        w, h = int(rs.randint(1, 48)), int(rs.randint(1, 48))
+        mrd = int(rs.choice([2, 3, 9, 10, 17, 18, 33, 100, 257, 700]))
+        view = View(cr - span_r / 2, ci - span_i / 2, span_r, span_i, w, h)
+        window = None
+        if w > 4 and h > 4 and k % 3 == 0:
+            c0, r0 = int(rs.randint(0, w - 2)), int(rs.randint(0, h - 2))
+            window = (c0, r0, int(rs.randint(1, w - c0 + 1)), int(rs.randint(1, h - r0 + 1)))
+        c, b, st = gpu.compute_view(view, mrd, window=window, precision=precision)
+        oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, w, h, mrd,
+                                    window=window, precision=precision)
+        assert np.array_equal(c, oc), (k, view, mrd, window, int((c != oc).sum()))
+        assert np.array_equal(b, ob) and st.pixel_iterations == total, (k, view, mrd)
