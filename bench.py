@@ -220,8 +220,9 @@ def main():
     if rank == 0:
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
         cus, mhz = device_info["compute_units"], device_info["clock_mhz"]
-        peak_lane_ops = cus * 4 * 16 * mhz * 1e6              # fp64 VALU lane-ops/s (16 lanes/clk/SIMD)
-        peak_tflops = peak_lane_ops * 2 / 1e12                 # FMA = 2 flop -> 78.6 on MI355X
+        lanes_per_clk = 16 if args.precision == "f64" else 32  # per SIMD: fp64 16, fp32 32 (SIMD-32)
+        peak_lane_ops = cus * 4 * lanes_per_clk * mhz * 1e6    # VALU lane-ops/s of that type
+        peak_tflops = peak_lane_ops * 2 / 1e12                 # FMA = 2 flop -> 78.6 (fp64) / 157.3 (fp32)
         achieved_tflops = FLOPS_PER_PIXEL_ITER * iters_per_step / avg_kernel_s / 1e12
         slots = VALU_SLOTS_PER_PIXEL_ITER.get(args.kernel, 8.0)
         out_bytes = npix * 4
@@ -246,7 +247,7 @@ def main():
                        "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus,
                        "clock_mhz": mhz},
             "roofline": {
-                "bound": "fp64_valu",
+                "bound": "fp64_valu" if args.precision == "f64" else "fp32_valu",
                 "achieved": achieved_tflops,
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",

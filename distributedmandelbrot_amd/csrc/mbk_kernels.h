@@ -14,9 +14,10 @@
 //   * squares are shared between the bailout test of step n and the update of step n+1 (same
 //     operands, same operation, same rounding).
 //
-// Roofline that bounds these kernels: fp64 VALU issue rate (not HBM, not MFMA): 7 fp64 VALU
-// operations per pixel-iteration (3 mul, 3 add, 1 fma) + one 32-bit compare; algorithmic HBM traffic
-// is the 4 B (int32) and/or 1 B (uint8) written per pixel, nothing is read.
+// Roofline that bounds these kernels: fp64 VALU issue rate (not HBM, not MFMA): 6 fp64 VALU
+// operations per pixel-iteration (3 mul, 2 add, 1 fma) plus the bailout test (1 add + 1 v_cmp, each a
+// full issue slot on gfx950) -- per step in kernels "simple"/"asm", once per 8 steps in "group";
+// algorithmic HBM traffic is the 4 B (int32) and/or 1 B (uint8) written per pixel, nothing is read.
 #pragma once
 
 #include <hip/hip_runtime.h>

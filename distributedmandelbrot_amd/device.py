@@ -80,6 +80,7 @@ class MandelbrotDevice:
         self._h = h
         self.device = device
         self._pinned = []
+        self._ser_buf = np.empty(1 + L.MBK_CHUNK_BYTES, np.uint8)   # reused by serialize_last
 
     # -- lifecycle -------------------------------------------------------------------------
     def close(self) -> None:
@@ -190,9 +191,7 @@ class MandelbrotDevice:
         """The last tile's quantised bytes exactly as DataChunk.Serialize (DataChunk.cs:173-206) would
         write them (code byte + Raw or RLE payload, the shorter; Raw on ties), encoded on the GPU.
         Returns (stream, codec)."""
-        cap = 1 + L.MBK_CHUNK_BYTES if not hasattr(self, "_ser_buf") else len(self._ser_buf)
-        if not hasattr(self, "_ser_buf"):
-            self._ser_buf = np.empty(cap, np.uint8)
+        cap = len(self._ser_buf)
         size, codec = C.c_uint64(0), C.c_uint32(0)
         st = self._lib.mbk_serialize_last(self._h, self._ser_buf.ctypes.data, cap, C.byref(size), C.byref(codec))
         if st == L.MBK_ERR_INVALID and size.value > cap:

@@ -10,6 +10,7 @@ for f in sorted(os.listdir(src)):
         lines = [l for l in open(os.path.join(src, f)) if l.startswith("{")]
         if lines:
             name = "bench_cfg2_default.json" if f == "bench.log" else f.replace(".log", ".json").replace("bench_", "bench_cfg2_" if f[6:-4] in ("asm", "simple", "refill", "group") else "bench_")
+            name = name.replace("bench_cfg2_f32", "bench_cfg2_f32")
             open(os.path.join(dst, name), "w").write(lines[-1])
 out = {}
 for d in ["prof_pmc", "prof_pmc_w", "prof_pmc_f"]:

@@ -22,6 +22,9 @@ done
 for W in ${BENCH_WORKLOADS:-}; do
   timeout 300 python bench.py --steps 5 --warmup 1 --workload $W --no-cpu-baseline > "$OUT/bench_$W.log" 2>&1; tail -1 "$OUT/bench_$W.log"
 done
+for W in ${BENCH_F32_WORKLOADS:-}; do
+  timeout 600 python bench.py --steps 3 --warmup 1 --workload $W --precision f32 --no-cpu-baseline > "$OUT/bench_${W}_f32.log" 2>&1; tail -1 "$OUT/bench_${W}_f32.log"
+done
 echo "== rocprofv3 kernel trace"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_trace" -o bench -- python "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_trace.log" 2>&1; echo "rocprof rc=$?")
 find "$OUT/prof_trace" -name "*stats*" | head; for f in $(find "$OUT/prof_trace" -name "*kernel_stats*.csv" | head -1); do head -8 "$f"; done
