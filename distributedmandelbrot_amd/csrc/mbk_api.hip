@@ -11,12 +11,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
 
 #include "mbk_kernels.h"
 #include "mbk_refill.h"
+#include "mbk_persist.h"
 
 using mbk::Axis;
 using mbk::ReduceOut;
@@ -43,7 +45,7 @@ struct mbk_ctx {
     uint8_t *d_rle = nullptr;        // RLE scratch: block counts | run starts | run values | output stream
     size_t rle_cap_px = 0;
     unsigned queue_turn = 0;
-    unsigned rf_livemin = 48, rf_patience = 32, rf_waves_per_simd = 8, rf_batch = 4, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32, group_steps = 8, rf_grouped = 1;  // tunables (MBK_* env)
+    unsigned rf_livemin = 48, rf_patience = 256, rf_waves_per_simd = 8, rf_batch = 1, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32, group_steps = 8, exact_steps = 8;  // tunables (MBK_* env)
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -159,6 +161,126 @@ static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling, b
     return MBK_OK;
 }
 
+// Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
+// (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
+static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, bool f32, hipStream_t stream)
+{
+    const uint32_t wpw = ctx->waves_per_wg;  // 8x8-pixel blocks (= waves) per workgroup
+    a.blocks_x = (a.ncols + 8u * wpw - 1u) / (8u * wpw);
+    const uint32_t by = (a.nrows + 7u) / 8u;
+    const dim3 grid(a.blocks_x * by), block(64u * wpw);
+    a.perm_mul = ctx->order == 1 ? coprime_multiplier(grid.x) : 1u;
+    a.order = nullptr;
+    if (ctx->order == 2 && grid.x >= 4096u && (uint32_t)a.mrd > 2u * ctx->probe_steps) {
+        // heavy-first dispatch order (see classify_blocks_kernel); tiny launches skip it
+        if (grid.x > ctx->order_cap) {
+            if (ctx->d_order) (void)hipFree(ctx->d_order);
+            ctx->d_order = nullptr;
+            ctx->order_cap = 0;
+            MBK_HIP(ctx, hipMalloc((void **)&ctx->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t) * kQueueRing));
+            ctx->order_cap = grid.x;
+        }
+        uint32_t *ord = ctx->d_order + (ctx->order_cap + 2u) * (ctx->queue_turn++ % kQueueRing);
+        uint32_t *cursors = ord + ctx->order_cap;
+        MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 2 * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, stream, a,
+                           grid.x, 8u * wpw, (int32_t)ctx->probe_steps, ord, cursors);
+        a.order = ord;
+    }
+    // dynamic LDS is never touched: it only caps how many workgroups a CU admits
+    if (f32 && safe)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, ctx->lds_pad, stream, a);
+    else if (f32 && kernel == MBK_KERNEL_ASM)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, ctx->lds_pad, stream, a);
+    else if (f32)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, ctx->lds_pad, stream, a);
+    else if (safe)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, ctx->lds_pad, stream, a);
+    else if (kernel == MBK_KERNEL_ASM)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, ctx->lds_pad, stream, a);
+    else if (ctx->group_steps == 8)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, ctx->lds_pad, stream, a);
+    else
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, ctx->lds_pad, stream, a);
+    MBK_HIP(ctx, hipGetLastError());
+    return MBK_OK;
+}
+
+// Can any pixel of the window lie within the ring | |c|^2 - 4 | < 1e-6 ?  (conservative rectangle test)
+static bool window_may_touch_ring(const TileArgs &a)
+{
+    const double x0 = axis_value_host(a.re, a.col0), x1 = axis_value_host(a.re, a.col0 + a.ncols - 1u);
+    const double y0 = axis_value_host(a.im, a.row0), y1 = axis_value_host(a.im, a.row0 + a.nrows - 1u);
+    const double xlo = std::fmin(x0, x1), xhi = std::fmax(x0, x1), ylo = std::fmin(y0, y1), yhi = std::fmax(y0, y1);
+    const double dx = (xlo <= 0.0 && 0.0 <= xhi) ? 0.0 : std::fmin(std::fabs(xlo), std::fabs(xhi));
+    const double dy = (ylo <= 0.0 && 0.0 <= yhi) ? 0.0 : std::fmin(std::fabs(ylo), std::fabs(yhi));
+    const double fx = std::fmax(std::fabs(xlo), std::fabs(xhi)), fy = std::fmax(std::fabs(ylo), std::fabs(yhi));
+    const double rmin2 = dx * dx + dy * dy, rmax2 = fx * fx + fy * fy;
+    return !(rmax2 < 4.0 - 1e-6 || rmin2 > 4.0 + 1e-6);
+}
+
+// Kernel "refill": persistent lane-refill kernel on the interior blocks + "group" on the edge strips.
+// Falls back to "group" for everything the narrow persistent kernel excludes (see mbk_persist.h).
+static int launch_refill(mbk_ctx *ctx, const TileArgs &a, bool safe, hipStream_t stream)
+{
+    const bool eligible = !safe && a.mrd >= 2 && a.counts != nullptr && !a.re.step_is_zero &&
+                          !a.im.step_is_zero && !window_may_touch_ring(a);
+    // interior = whole 8x8 blocks that do not contain the last sample of either axis
+    const uint32_t cols_ok = a.re.n > 0 ? std::min<uint64_t>(a.ncols, (uint64_t)(a.re.n - 1u) - std::min<uint64_t>(a.col0, a.re.n - 1u)) : 0u;
+    const uint32_t rows_ok = a.im.n > 0 ? std::min<uint64_t>(a.nrows, (uint64_t)(a.im.n - 1u) - std::min<uint64_t>(a.row0, a.im.n - 1u)) : 0u;
+    const uint32_t icols = eligible ? (cols_ok / 8u) * 8u : 0u, irows = eligible ? (rows_ok / 8u) * 8u : 0u;
+    if (icols == 0 || irows == 0) return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, false, stream);
+
+    mbk::PersistArgs q;
+    q.re_start = a.re.start;
+    q.re_step = a.re.step;
+    q.im_start = a.im.start;
+    q.im_step = a.im.step;
+    q.col0 = a.col0;
+    q.row0 = a.row0;
+    q.pitch = a.out_pitch;
+    q.bxn = icols / 8u;
+    q.nblocks = q.bxn * (irows / 8u);
+    q.total = (uint32_t)a.mrd - 1u;
+    q.livemin = ctx->rf_livemin;
+    q.patience = ctx->rf_patience;
+    q.batch = ctx->rf_batch;
+    q.counts = a.counts;
+    WorkQueues *wq = ctx->d_queues + (ctx->queue_turn++ % kQueueRing);
+    hipLaunchKernelGGL(mbk::init_queues_kernel, dim3(1), dim3(64), 0, stream, wq, q.nblocks);
+    uint32_t waves = (uint32_t)ctx->prop.multiProcessorCount * 4u * ctx->rf_waves_per_simd;
+    if (waves > q.nblocks) waves = q.nblocks;
+    hipLaunchKernelGGL(mbk::tile_persist_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, stream, q, wq);
+    MBK_HIP(ctx, hipGetLastError());
+    // edge strips through the ordinary kernel, written into the same output image
+    TileArgs e = a;
+    e.bytes = nullptr;
+    if (icols < a.ncols) {  // right strip, all rows
+        e.col0 = a.col0 + icols;
+        e.ncols = a.ncols - icols;
+        e.out_col0 = a.out_col0 + icols;
+        int rc = launch_blocks(ctx, e, MBK_KERNEL_GROUP, safe, false, stream);
+        if (rc != MBK_OK) return rc;
+    }
+    if (irows < a.nrows) {  // bottom strip, interior columns only
+        e = a;
+        e.bytes = nullptr;
+        e.ncols = icols;
+        e.row0 = a.row0 + irows;
+        e.nrows = a.nrows - irows;
+        e.out_row0 = a.out_row0 + irows;
+        int rc = launch_blocks(ctx, e, MBK_KERNEL_GROUP, safe, false, stream);
+        if (rc != MBK_OK) return rc;
+    }
+    if (a.bytes) {
+        const uint64_t npx = (uint64_t)a.ncols * a.nrows;
+        hipLaunchKernelGGL(mbk::quantise_kernel, dim3(2048), dim3(256), 0, stream, a.counts, a.bytes, npx, a.mrd,
+                           a.quant_wide);
+        MBK_HIP(ctx, hipGetLastError());
+    }
+    return MBK_OK;
+}
+
 static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t flags,
                        int32_t *d_counts, uint8_t *d_bytes, hipStream_t stream, double *d_smooth = nullptr)
 {
@@ -174,18 +296,20 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     if (wb && mrd == 0) return fail(ctx, MBK_ERR_INVALID, "mrd == 0 has no quantised form (division by zero)");
 
     TileArgs a;
+    std::memset(&a, 0, sizeof(a));
     a.re = make_axis(v->start_r, v->range_r, v->width);
     a.im = make_axis(v->start_i, v->range_i, v->height);
     a.col0 = v->col0;
     a.row0 = v->row0;
     a.ncols = v->ncols;
     a.nrows = v->nrows;
+    a.out_pitch = v->ncols;
+    a.out_col0 = 0;
+    a.out_row0 = 0;
     a.mrd = (int32_t)mrd;
     a.quant_wide = (mrd >= (1u << 23)) ? 1u : 0u;
-    a.rf_livemin = ctx->rf_livemin;
-    a.rf_patience = ctx->rf_patience;
-    a.rf_batch = ctx->rf_batch;
     a.perm_mul = 1u;
+    a.exact_steps = ctx->exact_steps;
     a.order = nullptr;
     a.counts = wc ? d_counts : nullptr;
     a.bytes = wb ? d_bytes : nullptr;
@@ -199,76 +323,15 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
         case MBK_KERNEL_GROUP:
-        case MBK_KERNEL_ASM: {
-            const uint32_t wpw = ctx->waves_per_wg;  // 8x8-pixel blocks (= waves) per workgroup
-            a.blocks_x = (v->ncols + 8u * wpw - 1u) / (8u * wpw);
-            const uint32_t by = (v->nrows + 7u) / 8u;
-            const dim3 grid(a.blocks_x * by), block(64u * wpw);
-            a.perm_mul = ctx->order == 1 ? coprime_multiplier(grid.x) : 1u;
-            if (ctx->order == 2 && grid.x >= 4096u && mrd > 2u * ctx->probe_steps) {
-                // heavy-first dispatch order (see classify_blocks_kernel); tiny launches skip it
-                if (grid.x > ctx->order_cap) {
-                    if (ctx->d_order) (void)hipFree(ctx->d_order);
-    if (ctx->d_rle) (void)hipFree(ctx->d_rle);
-    if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
-                    ctx->d_order = nullptr;
-                    ctx->order_cap = 0;
-                    MBK_HIP(ctx, hipMalloc((void **)&ctx->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t) * kQueueRing));
-                    ctx->order_cap = grid.x;
-                }
-                uint32_t *ord = ctx->d_order + (ctx->order_cap + 2u) * (ctx->queue_turn++ % kQueueRing);
-                uint32_t *cursors = ord + ctx->order_cap;
-                MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 2 * sizeof(uint32_t), stream));
-                hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0,
-                                   stream, a, grid.x, 8u * wpw, (int32_t)ctx->probe_steps, ord, cursors);
-                a.order = ord;
-            }
-            // dynamic LDS is never touched: it only caps how many workgroups a CU admits
-            if (f32 && safe)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, ctx->lds_pad, stream, a);
-            else if (f32 && kernel == MBK_KERNEL_ASM)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, ctx->lds_pad, stream, a);
-            else if (f32)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, ctx->lds_pad, stream, a);
-            else if (safe)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, ctx->lds_pad, stream, a);
-            else if (kernel == MBK_KERNEL_ASM)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, ctx->lds_pad, stream, a);
-            else if (ctx->group_steps == 8)
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, ctx->lds_pad, stream, a);
-            else
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, ctx->lds_pad, stream, a);
-            break;
-        }
-        case MBK_KERNEL_REFILL: {
-            if (mrd < 2) {  // nothing to iterate: the plain kernel writes the zeros
-                a.blocks_x = (v->ncols + 31u) / 32u;
-                const dim3 grid(a.blocks_x * ((v->nrows + 7u) / 8u)), block(256);
-                hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, 0, stream, a);
-                break;
-            }
-            const uint32_t nblocks = ((v->ncols + 7u) / 8u) * ((v->nrows + 7u) / 8u);
-            WorkQueues *wq = ctx->d_queues + (ctx->queue_turn++ % kQueueRing);
-            hipLaunchKernelGGL(mbk::init_queues_kernel, dim3(1), dim3(64), 0, stream, wq, nblocks);
-            uint32_t waves = (uint32_t)ctx->prop.multiProcessorCount * 4u * ctx->rf_waves_per_simd;
-            if (waves > nblocks) waves = nblocks;
-            const dim3 grid((waves + 3u) / 4u), block(256);
-            if (safe)
-                hipLaunchKernelGGL((mbk::tile_refill_kernel<false, false>), grid, block, 0, stream, a, wq);
-            else if (ctx->rf_grouped)
-                hipLaunchKernelGGL((mbk::tile_refill_kernel<true, true>), grid, block, 0, stream, a, wq);
-            else
-                hipLaunchKernelGGL((mbk::tile_refill_kernel<true, false>), grid, block, 0, stream, a, wq);
-            break;
-        }
+        case MBK_KERNEL_ASM:
+            return launch_blocks(ctx, a, kernel, safe, f32, stream);
+        case MBK_KERNEL_REFILL:
+            return launch_refill(ctx, a, safe, stream);
         case MBK_KERNEL_SIMPLE: {
             a.blocks_x = (v->ncols + 31u) / 32u;
             const uint32_t by = (v->nrows + 7u) / 8u;
             const dim3 grid(a.blocks_x * by), block(256);
-            if (safe || kernel == MBK_KERNEL_SIMPLE)
-                hipLaunchKernelGGL(mbk::tile_simple_kernel<false>, grid, block, 0, stream, a);
-            else
-                hipLaunchKernelGGL(mbk::tile_simple_kernel<true>, grid, block, 0, stream, a);
+            hipLaunchKernelGGL(mbk::tile_simple_kernel<false>, grid, block, 0, stream, a);
             break;
         }
         default:
@@ -352,7 +415,7 @@ int mbk_create(int device, mbk_ctx **out)
     if (const char *e = std::getenv("MBK_RF_LIVEMIN")) ctx->rf_livemin = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_RF_PATIENCE")) ctx->rf_patience = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_WPW")) { unsigned w = (unsigned)std::atoi(e); if (w == 1 || w == 2 || w == 4) ctx->waves_per_wg = w; }
-    if (const char *e = std::getenv("MBK_RF_GROUPED")) ctx->rf_grouped = (unsigned)std::atoi(e);
+    if (const char *e = std::getenv("MBK_EXACT")) ctx->exact_steps = (unsigned)std::atoi(e);
     if (const char *e = std::getenv("MBK_GROUP")) ctx->group_steps = (unsigned)std::atoi(e) == 4 ? 4u : 8u;
     if (const char *e = std::getenv("MBK_PROBE")) ctx->probe_steps = (unsigned)std::atoi(e) > 1 ? (unsigned)std::atoi(e) : 2u;
     if (const char *e = std::getenv("MBK_LDS")) ctx->lds_pad = (unsigned)std::atoi(e);

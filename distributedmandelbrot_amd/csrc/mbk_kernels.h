@@ -40,11 +40,10 @@ struct TileArgs {
     Axis re, im;
     uint32_t col0, row0, ncols, nrows;
     uint32_t blocks_x;    // workgroups per row of 8-pixel-high block rows (1-D grid)
+    uint32_t out_pitch, out_col0, out_row0;  // output element = (row + out_row0) * out_pitch + col + out_col0
     int32_t mrd;
     uint32_t quant_wide;  // 1: count*256+mrd-1 does not fit 32 bits -> 64-bit quantiser division
-    uint32_t rf_livemin;  // refill kernel policy: leave the hot loop when <= this many lanes are live
-    uint32_t rf_patience; // ... or this many steps after the first unrefilled escape
-    uint32_t rf_batch;    // 8x8 blocks taken per queue pop
+    uint32_t exact_steps; // steps tested one by one before the grouped test takes over
     uint32_t perm_mul;    // workgroup order: block = (blockIdx * perm_mul) mod gridDim (1 = row-major)
     const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel)
     int32_t *counts;      // may be null
@@ -181,11 +180,11 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
         const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
         const bool risky = __any(c2 > (T)4 - margin && c2 < (T)4 + margin) != 0;
         count = risky ? escape_count_asm<true>(cr, ci, p.mrd, &m)
-                      : escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd, &m);
+                      : escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd, &m, p.exact_steps);
     } else {
         count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd, &m);
     }
-    const size_t o = (size_t)lr * p.ncols + lc;
+    const size_t o = (size_t)(lr + p.out_row0) * p.out_pitch + lc + p.out_col0;
     if (p.counts) p.counts[o] = count;
     if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
     if (p.smooth) p.smooth[o] = smooth_value(count, (double)m);

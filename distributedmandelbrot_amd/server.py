@@ -147,9 +147,10 @@ class Distributer(_TcpLoop):
                         del self.leases[k]
                         break
                 self.completed.add((w[0], w[2], w[3]))
-                self.received += 1
-            if self.store is not None:
+            if self.store is not None:  # the reference saves on a thread-pool task (Distributer.cs:436-442)
                 self.store.save_chunk(w[0], w[2], w[3], payload)
+            with self._state:
+                self.received += 1      # counts tiles that are accepted AND stored
         else:
             self.errors.append(f"unknown connection purpose {op}")
 
