@@ -67,6 +67,10 @@ def parse_args():
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
                     help="f32 = BASELINE cfg4's fp32 kernel variant (not in the reference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", default="tiles", choices=["tiles", "bands"],
+                    help="tiles (default): every rank computes its own tile per step (weak scaling). bands: ONE "
+                         "view per step is split into 128-row bands interleaved over the ranks (strong scaling; "
+                         "how BASELINE cfg3 shards an image over 8 GPUs)")
     ap.add_argument("--streams", type=int, default=1,
                     help="tiles in flight per GPU: steps are issued round-robin on this many HIP streams "
                          "(1 = the contract's serial steps; 2 lets the next tile fill the drain of the last)")
@@ -94,9 +98,16 @@ def cpu_baseline(workload, precision="f64"):
                             want_bytes=False, nthreads=cores, precision=precision)[2]
         sample = f"every {stride}th 8-row band of the {w}x{h} tile ({len(bands) * 8} rows)"
     dt = time.perf_counter() - t0
-    return {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
-            "sample": sample + f", mrd {mrd}, C oracle gcc -O2 -ffp-contract=off, OpenMP dynamic rows",
-            "seconds": dt}
+    rec = {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
+           "sample": sample + f", mrd {mrd}, C oracle gcc -O2 -ffp-contract=off, OpenMP dynamic rows",
+           "seconds": dt}
+    if precision == "f64" and stride == 1 and o.have_avx512():
+        # best-effort CPU: the same strict arithmetic 8 pixels at a time in AVX-512 (no fmadd), same threads
+        t0 = time.perf_counter()
+        _, total8 = o.view_avx512(sr, si, rng, rng, w, h, mrd, want_counts=False, nthreads=cores)
+        dt8 = time.perf_counter() - t0
+        rec["best_effort_avx512"] = {"value": total8 / dt8 / 1e9, "seconds": dt8, "bit_identical_work": total8 == total}
+    return rec
 
 
 def pmc_traffic(workload, kernel):
@@ -166,11 +177,20 @@ def main():
         stream = streams[0]
         turn = [0]
 
+        from distributedmandelbrot_amd.sharding import make_bands, rank_bands
+        my_bands = rank_bands(make_bands(height, 128), rank, world) if args.shard == "bands" else None
+
         def launch():
             i = turn[0] % nstreams
             turn[0] += 1
-            dev.launch_view(view, mrd, d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
-                            kernel=args.kernel, precision=args.precision)
+            if my_bands is None:
+                dev.launch_view(view, mrd, d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
+                                kernel=args.kernel, precision=args.precision)
+            else:  # this rank's row bands of the shared view, each written at its place in the image
+                for bnd in my_bands:
+                    dev.launch_view(view, mrd, window=(0, bnd.row0, width, bnd.nrows),
+                                    d_counts=d_counts_all[i].data_ptr() + 4 * bnd.row0 * width,
+                                    stream=streams[i].cuda_stream, kernel=args.kernel, precision=args.precision)
             return streams[i]
 
         def sync():
@@ -201,8 +221,16 @@ def main():
         kernel_ms = [elapsed / args.steps * 1e3] * args.steps
         never = 0
     else:
-        st = dev.reduce_counts(d_counts.data_ptr(), npix, mrd, stream=stream.cuda_stream)
-        iters_per_step, never = st.pixel_iterations, st.never_pixels
+        if my_bands is None:
+            st = dev.reduce_counts(d_counts.data_ptr(), npix, mrd, stream=stream.cuda_stream)
+            iters_per_step, never = st.pixel_iterations, st.never_pixels
+        else:
+            iters_per_step = never = 0
+            for bnd in my_bands:
+                st = dev.reduce_counts(d_counts.data_ptr() + 4 * bnd.row0 * width, bnd.nrows * width, mrd,
+                                       stream=stream.cuda_stream)
+                iters_per_step += st.pixel_iterations
+                never += st.never_pixels
         kernel_ms = [a.elapsed_time(b) for a, b in events]
 
     # max elapsed over ranks, total work over ranks
@@ -235,7 +263,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.shard == "tiles" else "strong",
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic (coordinates generated in-kernel from the view origin and stride; no RNG)",
@@ -243,7 +271,7 @@ def main():
                                    "written to resident HBM", "kernel": args.kernel,
                        "pixels_per_step_per_gpu": npix, "pixel_iterations_per_step_per_gpu": iters_per_step,
                        "never_escaped_pixels": never, "parallelism": f"{world} independent tile queue(s), no collective",
-                       "streams_per_gpu": max(1, args.streams),
+                       "streams_per_gpu": max(1, args.streams), "shard": args.shard,
                        "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus,
                        "clock_mhz": mhz},
             "roofline": {

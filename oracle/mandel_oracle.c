@@ -244,6 +244,86 @@ uint64_t mbo_datachunk(uint32_t level, uint32_t mrd, uint32_t index_real, uint32
                     bytes, nthreads);
 }
 
+/*
+ * "Best-effort CPU" baseline (bench.py only): the same strict arithmetic, 8 pixels at a time in AVX-512
+ * registers -- explicit mul/add/sub intrinsics, never fmadd, so the counts are bit-identical to
+ * mbo_escape.  Processes one row segment; lanes that escaped keep iterating harmlessly (their count is
+ * frozen), the loop ends when all 8 are done or after mrd-1 steps.  Returns pixel-iterations.
+ * Compiled only where the compiler supports the target attribute; selected at run time.
+ */
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+#define MBO_HAVE_AVX512 1
+__attribute__((target("avx512f"))) static uint64_t mbo_row_avx512(const double *xr, double ci, uint32_t ncols,
+                                                                   int32_t mrd, int32_t *counts)
+{
+    uint64_t iters = 0;
+    const __m512d four = _mm512_set1_pd(4.0), two = _mm512_set1_pd(2.0), vci = _mm512_set1_pd(ci);
+    for (uint32_t c0 = 0; c0 < ncols; c0 += 8) {
+        const uint32_t nv = ncols - c0 < 8 ? ncols - c0 : 8;
+        const __mmask8 valid = (__mmask8)((1u << nv) - 1u);
+        const __m512d vcr = _mm512_maskz_loadu_pd(valid, xr + c0);
+        __m512d zr = vcr, zi = vci;
+        __m512i cnt = _mm512_setzero_si512();
+        __mmask8 live = valid;
+        for (int32_t n = 1; n < mrd && live; ++n) {
+            const __m512d a = _mm512_mul_pd(zr, zr), b = _mm512_mul_pd(zi, zi);
+            const __m512d t = _mm512_sub_pd(a, b);
+            const __m512d u = _mm512_mul_pd(_mm512_mul_pd(two, zr), zi);
+            zr = _mm512_add_pd(t, vcr);
+            zi = _mm512_add_pd(u, vci);
+            const __m512d m = _mm512_add_pd(_mm512_mul_pd(zr, zr), _mm512_mul_pd(zi, zi));
+            const __mmask8 esc = _mm512_mask_cmp_pd_mask(live, m, four, _CMP_GE_OQ);
+            cnt = _mm512_mask_mov_epi64(cnt, esc, _mm512_set1_epi64(n));
+            live &= (__mmask8)~esc;
+        }
+        long long tmp[8];
+        _mm512_storeu_si512((void *)tmp, cnt);
+        for (uint32_t k = 0; k < nv; ++k) {
+            if (counts) counts[c0 + k] = (int32_t)tmp[k];
+            iters += tmp[k] > 0 ? (uint64_t)tmp[k] : (uint64_t)(mrd > 1 ? mrd - 1 : 0);
+        }
+    }
+    return iters;
+}
+#endif
+
+int mbo_have_avx512(void)
+{
+#ifdef MBO_HAVE_AVX512
+    return __builtin_cpu_supports("avx512f") ? 1 : 0;
+#else
+    return 0;
+#endif
+}
+
+/* Whole view with the AVX-512 row kernel (counts optional).  Returns 0 if AVX-512 is unavailable. */
+uint64_t mbo_view_avx512(double start_r, double start_i, double range_r, double range_i, uint32_t width,
+                         uint32_t height, int32_t mrd, int32_t *counts, int nthreads)
+{
+#ifdef MBO_HAVE_AVX512
+    if (!mbo_have_avx512()) return 0;
+    double *xr = (double *)malloc(sizeof(double) * (width ? width : 1));
+    double *xi = (double *)malloc(sizeof(double) * (height ? height : 1));
+    mbo_axis(start_r, range_r, width, xr);
+    mbo_axis(start_i, range_i, height, xi);
+    uint64_t total = 0;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : total)
+#endif
+    for (int64_t r = 0; r < (int64_t)height; ++r)
+        total += mbo_row_avx512(xr, xi[r], width, mrd, counts ? counts + (size_t)r * width : NULL);
+    free(xr);
+    free(xi);
+    return total;
+#else
+    (void)start_r; (void)start_i; (void)range_r; (void)range_i; (void)width; (void)height; (void)mrd;
+    (void)counts; (void)nthreads;
+    return 0;
+#endif
+}
+
 int mbo_max_threads(void)
 {
 #ifdef _OPENMP

@@ -60,6 +60,10 @@ class COracle:
                                     C.c_void_p, C.c_void_p, C.c_int]
         L.mbo_datachunk.restype = C.c_uint64
         L.mbo_max_threads.restype = C.c_int
+        L.mbo_have_avx512.restype = C.c_int
+        L.mbo_view_avx512.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
+                                      C.c_int32, C.c_void_p, C.c_int]
+        L.mbo_view_avx512.restype = C.c_uint64
 
     def max_threads(self) -> int:
         return int(self.lib.mbo_max_threads())
@@ -100,6 +104,16 @@ class COracle:
         self.lib.mbo_view_smooth(start_r, start_i, range_r, range_i, width, height, mrd,
                                  smooth.ctypes.data, counts.ctypes.data)
         return smooth, counts
+
+    def have_avx512(self) -> bool:
+        return bool(self.lib.mbo_have_avx512())
+
+    def view_avx512(self, start_r, start_i, range_r, range_i, width, height, mrd, *, want_counts=True, nthreads=0):
+        """The 8-lane AVX-512 evaluation (bench.py's best-effort CPU baseline): (counts | None, pixel_iters)."""
+        counts = np.empty((height, width), np.int32) if want_counts else None
+        total = self.lib.mbo_view_avx512(start_r, start_i, range_r, range_i, width, height, mrd,
+                                         counts.ctypes.data if want_counts else None, nthreads)
+        return counts, int(total)
 
     def datachunk(self, level, mrd, index_real, index_imag, *, want_counts=True, nthreads=0):
         counts = np.empty((4096, 4096), dtype=np.int32) if want_counts else None

@@ -160,3 +160,13 @@ def test_smooth_oracle_consistency(oracle):
     import ctypes as C
     v.restype = C.c_double; v.argtypes = [C.c_double, C.c_double, C.c_int32, C.c_void_p]
     assert abs(v(2.0, 2.0, 10, None) - (2.0 - np.log2(0.5 * np.log(104.0)))) < 1e-15
+
+
+def test_avx512_baseline_is_bit_identical_to_scalar_oracle(oracle):
+    if not oracle.have_avx512():
+        pytest.skip("host CPU has no AVX-512")
+    for sr, si, rr, ri, w, h, mrd in [(-2.0, -1.5, 3.0, 3.0, 203, 77, 300), (-0.755, 0.10, 0.02, 0.02, 64, 64, 2000),
+                                      (-2.0, -2.0, 4.0, 4.0, 9, 5, 2), (0.3, 0.3, 1e-3, 1e-3, 17, 3, 1)]:
+        c, _, total = oracle.view(sr, si, rr, ri, w, h, mrd, want_bytes=False)
+        c2, total2 = oracle.view_avx512(sr, si, rr, ri, w, h, mrd)
+        assert np.array_equal(c, c2) and total == total2
