@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "bands"],
                     help="tiles (default): every rank computes its own tile per step (weak scaling). bands: ONE "
-                         "view per step is split into 128-row bands interleaved over the ranks (strong scaling; "
+                         "view per step is split into row bands (4 per rank) interleaved over the ranks (strong scaling; "
                          "how BASELINE cfg3 shards an image over 8 GPUs)")
     ap.add_argument("--streams", type=int, default=1,
                     help="tiles in flight per GPU: steps are issued round-robin on this many HIP streams "
@@ -178,7 +178,8 @@ def main():
         turn = [0]
 
         from distributedmandelbrot_amd.sharding import make_bands, rank_bands
-        my_bands = rank_bands(make_bands(height, 128), rank, world) if args.shard == "bands" else None
+        band_rows = max(128, height // (4 * world))   # 4 interleaved slabs per rank: balance vs per-launch drain
+        my_bands = rank_bands(make_bands(height, band_rows), rank, world) if args.shard == "bands" else None
 
         def launch():
             i = turn[0] % nstreams
@@ -186,11 +187,13 @@ def main():
             if my_bands is None:
                 dev.launch_view(view, mrd, d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
                                 kernel=args.kernel, precision=args.precision)
-            else:  # this rank's row bands of the shared view, each written at its place in the image
-                for bnd in my_bands:
+            else:  # this rank's row bands of the shared view, each written at its place in the image;
+                # bands go round-robin over the streams so that one band's drain overlaps the next band
+                for j, bnd in enumerate(my_bands):
                     dev.launch_view(view, mrd, window=(0, bnd.row0, width, bnd.nrows),
-                                    d_counts=d_counts_all[i].data_ptr() + 4 * bnd.row0 * width,
-                                    stream=streams[i].cuda_stream, kernel=args.kernel, precision=args.precision)
+                                    d_counts=d_counts_all[0].data_ptr() + 4 * bnd.row0 * width,
+                                    stream=streams[j % nstreams].cuda_stream, kernel=args.kernel,
+                                    precision=args.precision)
             return streams[i]
 
         def sync():
