@@ -54,7 +54,7 @@ WORKLOADS = {
 FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
 # fp64-rate VALU issue slots each kernel spends per pixel-iteration (v_cmp costs a full slot on gfx950):
 #   per-step test: 3 mul + 3 add + 1 fma + 1 v_cmp = 8;  grouped test (default): 6 + 2 per 8 steps = 6.25
-VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.25, "group": 6.25, "asm": 8.0, "simple": 8.0, "refill": 8.0}
+VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.25, "group": 6.25, "refill": 6.25, "asm": 8.0, "simple": 8.0}
 
 
 def parse_args():
@@ -115,7 +115,7 @@ def pmc_traffic(workload, kernel):
     (profiles/r01/cfg2_default_pmc_summary.json: WRITE_SIZE and FETCH_SIZE are in KiB; FETCH_SIZE is
     doubled as MI355X_MICROARCH.md prescribes for gfx950).  None for un-profiled combinations -- PMC
     counters cannot be collected from inside the timed run itself."""
-    if workload != "cfg2" or kernel not in ("default", "asm"):
+    if workload != "cfg2" or kernel not in ("default", "group"):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "cfg2_default_pmc_summary.json")) as f:
@@ -283,7 +283,7 @@ def main():
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak_tflops,
-                "traffic": pmc_traffic(args.workload, args.kernel),
+                "traffic": pmc_traffic(args.workload, args.kernel) if args.precision == "f64" else None,
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_ms_min": min(kernel_ms),
                 "flops_per_pixel_iteration": FLOPS_PER_PIXEL_ITER,

@@ -115,7 +115,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     "v_cmp_ngt_f64 vcc, 4.0, %[m]\n"                       \
     "s_cbranch_vccnz .Lqrep" ID "_%=\n"                    \
     ".Lqcont" ID "_%=:\n"
-#define MBK_RFG_REPLAY_STEP(STEP, J)                       \
+#define MBK_RFG_REPLAY_STEP(STEP, J, ID)                   \
     STEP                                                   \
     "v_add_f64 %[m], %[at], %[bt]\n"                       \
     "v_cmp_le_f64 vcc, 4.0, %[m]\n"                        \
@@ -123,15 +123,17 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     "s_or_b64 %[esc], %[esc], vcc\n"                       \
     "s_and_saveexec_b64 %[tmp2], vcc\n"                    \
     "v_sub_u32 %[cnt], %[k], %[start]\n"                   \
-    "s_andn2_b64 exec, %[tmp2], vcc\n"
+    "s_andn2_b64 exec, %[tmp2], vcc\n"                     \
+    "s_cbranch_scc0 .Lqrepend" ID "_%=\n"   /* every tripped lane found: stop replaying */
 #define MBK_RFG_REPLAY8(FIRST, ID, J1, J2, J3, J4, J5, J6, J7, J8, NADV, COPYBACK) \
     ".Lqrep" ID "_%=:\n"                                   \
     "s_and_saveexec_b64 %[tmp], vcc\n"                     \
     "s_mov_b64 %[esc], 0\n"                                \
-    MBK_RFG_REPLAY_STEP(FIRST, J1) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J2) \
-    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J3) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J4) \
-    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J5) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J6) \
-    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J7) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J8) \
+    MBK_RFG_REPLAY_STEP(FIRST, J1, ID) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J2, ID) \
+    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J3, ID) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J4, ID) \
+    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J5, ID) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J6, ID) \
+    MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J7, ID) MBK_RFG_REPLAY_STEP(MBK_RFG_T2T, J8, ID) \
+    ".Lqrepend" ID "_%=:\n"                                \
     "s_andn2_b64 exec, %[tmp], %[esc]\n"                   \
     "s_cbranch_scc0 .Lqexit" ID "_%=\n"                    \
     "s_bcnt1_i32_b64 %[k2], exec\n"                        \

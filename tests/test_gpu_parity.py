@@ -1,6 +1,7 @@
 """GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI
 (libmbk_hip.so via ctypes); the CPU oracle and the committed golden vectors are the checkers.
 The bar is bit-exact: int32 escape indices and uint8 quantised bytes."""
+import ctypes as C
 import hashlib
 
 import numpy as np
@@ -111,6 +112,12 @@ def test_argument_errors(gpu):
         gpu.compute_view(v, 2 ** 31, want_bytes=False)                # int32 result type
     with pytest.raises(MbkError):
         gpu.compute_view(v, 10, window=(10, 0, 7, 16))                # window outside the view
+    with pytest.raises(MbkError):
+        gpu._check(gpu._lib.mbk_view_compute(gpu._h, C.byref(L.mbk_view(-2.0, -2.0, 4.0, 4.0, 16, 16, 0, 0, 0, 4)),
+                                             10, L.MBK_WANT_COUNTS, np.empty(4, np.int32).ctypes.data, None, None))  # empty window
+    with pytest.raises(MbkError):
+        gpu._check(gpu._lib.mbk_view_compute(gpu._h, C.byref(L.mbk_view(-2.0, -2.0, 4.0, 4.0, 0, 16, 0, 0, 1, 1)),
+                                             10, L.MBK_WANT_COUNTS, np.empty(4, np.int32).ctypes.data, None, None))  # empty view
     with pytest.raises(MbkError):
         gpu.compute_view(View(float("nan"), 0.0, 1.0, 1.0, 4, 4), 10)
     with pytest.raises(MbkError):
