@@ -66,3 +66,40 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "libmandel_oracle" not in text, f
+
+
+def test_header_is_plain_c_and_the_library_links_from_c(tmp_path):
+    """include/mbk.h must be consumable by a C compiler (the boundary is a C ABI, not C++), and a C
+    program must link against libmbk_hip.so and call the host-only entry points."""
+    import shutil
+    import subprocess
+    from distributedmandelbrot_amd import build
+    so = build.build()
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi_smoke.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include "mbk.h"
+int main(void) {
+    double sr, si, range;
+    mbk_view v = {-2.0, -1.5, 3.0, 3.0, 4096u, 4096u, 0u, 0u, 4096u, 4096u};
+    mbk_stats st; mbk_device_info info; (void)v; (void)st; (void)info;
+    if (mbk_abi_version() != MBK_ABI_VERSION) return 2;
+    if (mbk_datachunk_geometry(4u, 1u, 2u, &sr, &si, &range) != MBK_OK) return 3;
+    if (mbk_datachunk_geometry(4u, 4u, 0u, &sr, &si, &range) != MBK_ERR_INVALID) return 4;
+    mbk_datachunk_geometry(4u, 1u, 2u, &sr, &si, &range);
+    int n = -1; int rc = mbk_device_count(&n);
+    printf("%.17g %.17g %.17g %d %d %u\n", sr, si, range, rc == MBK_OK || rc == MBK_ERR_NO_DEVICE, n >= 0,
+           (unsigned)MBK_CHUNK_BYTES);
+    return 0;
+}
+""")
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(so)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-l:libmbk_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["-1", "0", "1", "1", "1", "16777216"]
