@@ -134,6 +134,9 @@ int mbk_datachunk_geometry(uint32_t level, uint32_t index_real, uint32_t index_i
  * with MBK_WANT_BYTES, the host quantiser (:96-98).  d_counts: int32[nrows*ncols] (or NULL without
  * MBK_WANT_COUNTS); d_bytes: uint8[nrows*ncols] (or NULL without MBK_WANT_BYTES).
  * mrd is the reference's "maximum recursion depth": at most mrd-1 updates, result in {0} U [1, mrd-1].
+ * A launch may enqueue small helper kernels (dispatch-order pre-pass, work-queue reset) that use
+ * per-ctx scratch from a ring of 8 slots: keep at most 8 launches of one ctx in flight ACROSS
+ * different streams (launches on one stream are ordered and may be queued without limit).
  */
 int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
                     int32_t *d_counts, uint8_t *d_bytes, void *hip_stream);
