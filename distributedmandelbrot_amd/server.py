@@ -136,8 +136,8 @@ class Distributer(_TcpLoop):
             with self._state:
                 live = any(lw == w and now < t for lw, t in self.leases)
             if not live:
-                c.sendall(bytes([0x21]))
                 self.rejected.append(w)
+                c.sendall(bytes([0x21]))
                 return
             c.sendall(bytes([0x20]))
             payload = np.frombuffer(_recv_exact(c, CHUNK_BYTES), dtype=np.uint8)

@@ -138,8 +138,8 @@ class FakeDistributer:
         w = struct.unpack("<IIII", self._recv_exact(c, 16))
         now = time.monotonic()
         if not self._live(w, now):
-            c.sendall(bytes([0x21]))
             self.rejected.append(w)
+            c.sendall(bytes([0x21]))
             return
         c.sendall(bytes([0x20]))
         if self.faithful_single_receive:
