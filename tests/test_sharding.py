@@ -80,9 +80,13 @@ def test_render_view_over_fake_devices_equals_whole_view(oracle):
 def test_bench_distributed_path_gloo_world2():
     """bench.py's N>1 path (barrier, per-rank shard, max-over-ranks timing, aggregate) with two CPU
     processes over gloo; the compute is a stub (MBK_BENCH_FAKE=1) because there is no GPU here."""
+    import socket
+    with socket.socket() as s_:            # a free rendezvous port (fixed ports collide between runs)
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
     env = dict(os.environ, MBK_BENCH_FAKE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
