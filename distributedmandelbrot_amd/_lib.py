@@ -26,6 +26,7 @@ KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MB
            "refill": MBK_KERNEL_REFILL, "group": MBK_KERNEL_GROUP}
 MBK_PRECISION_F32 = 0x1000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
+MBK_SLOTS = 2
 MBK_CODEC_RAW = 0x00
 MBK_CODEC_RLE = 0x01
 MBK_CHUNK_DEFINITION = 4096
@@ -77,6 +78,9 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "mbk_view_compute_smooth": (C.c_int, [C.c_void_p, C.POINTER(mbk_view), C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.POINTER(mbk_stats)]),
+    "mbk_datachunk_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_void_p, C.c_void_p]),
+    "mbk_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(mbk_stats)]),
     "mbk_serialize_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(C.c_uint32)]),
     "mbk_reduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,

@@ -27,8 +27,9 @@ using mbk::WorkQueues;
 
 static const int kQueueRing = 8;  // launches in flight on one ctx may overlap by this many
 
-struct mbk_ctx {
-    int device = -1;
+// One in-flight tile of the host-buffer API: its own stream (so that the D2H of one slot overlaps the
+// kernel of the other), events, device result buffers and reduction scratch.
+struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_c0 = nullptr, ev_c1 = nullptr;
     int32_t *d_counts = nullptr;
@@ -36,6 +37,13 @@ struct mbk_ctx {
     size_t cap_px = 0;
     ReduceOut *d_red = nullptr;
     ReduceOut *h_red = nullptr;  // pinned
+    bool busy = false;           // submitted, not yet waited for
+    bool with_bytes = false;
+};
+
+struct mbk_ctx {
+    int device = -1;
+    Slot s[MBK_SLOTS];
     WorkQueues *d_queues = nullptr;  // kQueueRing work-queue blocks for the persistent kernel
     uint32_t *d_order = nullptr;     // kQueueRing dispatch-order lists (+2 cursors each)
     size_t order_cap = 0;            // regions per list
@@ -341,42 +349,41 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     return MBK_OK;
 }
 
-static int ensure_buffers(mbk_ctx *ctx, size_t px)
+static int ensure_buffers(mbk_ctx *ctx, Slot &sl, size_t px)
 {
-    if (px <= ctx->cap_px) return MBK_OK;
-    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
-    if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
-    ctx->d_counts = nullptr;
-    ctx->d_bytes = nullptr;
-    ctx->cap_px = 0;
-    MBK_HIP(ctx, hipMalloc((void **)&ctx->d_counts, px * sizeof(int32_t)));
-    MBK_HIP(ctx, hipMalloc((void **)&ctx->d_bytes, px));
-    ctx->cap_px = px;
+    if (px <= sl.cap_px) return MBK_OK;
+    if (sl.d_counts) (void)hipFree(sl.d_counts);
+    if (sl.d_bytes) (void)hipFree(sl.d_bytes);
+    sl.d_counts = nullptr;
+    sl.d_bytes = nullptr;
+    sl.cap_px = 0;
+    MBK_HIP(ctx, hipMalloc((void **)&sl.d_counts, px * sizeof(int32_t)));
+    MBK_HIP(ctx, hipMalloc((void **)&sl.d_bytes, px));
+    sl.cap_px = px;
     return MBK_OK;
 }
 
-static int launch_reduce(mbk_ctx *ctx, const int32_t *d_counts, const uint8_t *d_bytes, uint64_t n,
+static int launch_reduce(mbk_ctx *ctx, Slot &sl, const int32_t *d_counts, const uint8_t *d_bytes, uint64_t n,
                          uint32_t mrd, hipStream_t stream)
 {
-    MBK_HIP(ctx, hipMemsetAsync(ctx->d_red, 0, sizeof(ReduceOut), stream));
+    MBK_HIP(ctx, hipMemsetAsync(sl.d_red, 0, sizeof(ReduceOut), stream));
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(mbk::reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
-                       d_bytes, n, mrd, ctx->d_red);
+                       d_bytes, n, mrd, sl.d_red);
     MBK_HIP(ctx, hipGetLastError());
-    MBK_HIP(ctx, hipMemcpyAsync(ctx->h_red, ctx->d_red, sizeof(ReduceOut), hipMemcpyDeviceToHost,
-                                stream));
+    MBK_HIP(ctx, hipMemcpyAsync(sl.h_red, sl.d_red, sizeof(ReduceOut), hipMemcpyDeviceToHost, stream));
     return MBK_OK;
 }
 
-static void fill_stats_from_reduce(const mbk_ctx *ctx, mbk_stats *s, bool have_bytes)
+static void fill_stats_from_reduce(const Slot &sl, mbk_stats *s, bool have_bytes)
 {
-    s->pixel_iterations = ctx->h_red->pixel_iterations;
-    s->never_pixels = ctx->h_red->never_pixels;
-    s->all_bytes_zero = have_bytes && ctx->h_red->any_byte_not_zero == 0 ? 1u : 0u;
-    s->all_bytes_one = have_bytes && ctx->h_red->any_byte_not_one == 0 ? 1u : 0u;
-    s->rle_runs = have_bytes ? ctx->h_red->run_starts : 0ull;
+    s->pixel_iterations = sl.h_red->pixel_iterations;
+    s->never_pixels = sl.h_red->never_pixels;
+    s->all_bytes_zero = have_bytes && sl.h_red->any_byte_not_zero == 0 ? 1u : 0u;
+    s->all_bytes_one = have_bytes && sl.h_red->any_byte_not_one == 0 ? 1u : 0u;
+    s->rle_runs = have_bytes ? sl.h_red->run_starts : 0ull;
 }
 
 // ------------------------------------- C ABI ---------------------------------------------------
@@ -439,14 +446,16 @@ int mbk_create(int device, mbk_ctx **out)
         mbk_destroy(ctx);
         return MBK_ERR_NO_DEVICE;
     }
-    MBK_CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_k0));
-    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_k1));
-    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_c0));
-    MBK_CREATE_HIP(hipEventCreate(&ctx->ev_c1));
-    MBK_CREATE_HIP(hipMalloc((void **)&ctx->d_red, sizeof(ReduceOut)));
+    for (Slot &sl : ctx->s) {
+        MBK_CREATE_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        MBK_CREATE_HIP(hipEventCreate(&sl.ev_k0));
+        MBK_CREATE_HIP(hipEventCreate(&sl.ev_k1));
+        MBK_CREATE_HIP(hipEventCreate(&sl.ev_c0));
+        MBK_CREATE_HIP(hipEventCreate(&sl.ev_c1));
+        MBK_CREATE_HIP(hipMalloc((void **)&sl.d_red, sizeof(ReduceOut)));
+        MBK_CREATE_HIP(hipHostMalloc((void **)&sl.h_red, sizeof(ReduceOut), hipHostMallocDefault));
+    }
     MBK_CREATE_HIP(hipMalloc((void **)&ctx->d_queues, sizeof(WorkQueues) * kQueueRing));
-    MBK_CREATE_HIP(hipHostMalloc((void **)&ctx->h_red, sizeof(ReduceOut), hipHostMallocDefault));
 #undef MBK_CREATE_HIP
     *out = ctx;
     return MBK_OK;
@@ -456,20 +465,22 @@ void mbk_destroy(mbk_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
-    if (ctx->d_bytes) (void)hipFree(ctx->d_bytes);
-    if (ctx->d_red) (void)hipFree(ctx->d_red);
+    for (Slot &sl : ctx->s) {
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        if (sl.d_counts) (void)hipFree(sl.d_counts);
+        if (sl.d_bytes) (void)hipFree(sl.d_bytes);
+        if (sl.d_red) (void)hipFree(sl.d_red);
+        if (sl.h_red) (void)hipHostFree(sl.h_red);
+        if (sl.ev_k0) (void)hipEventDestroy(sl.ev_k0);
+        if (sl.ev_k1) (void)hipEventDestroy(sl.ev_k1);
+        if (sl.ev_c0) (void)hipEventDestroy(sl.ev_c0);
+        if (sl.ev_c1) (void)hipEventDestroy(sl.ev_c1);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
     if (ctx->d_queues) (void)hipFree(ctx->d_queues);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_rle) (void)hipFree(ctx->d_rle);
     if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
-    if (ctx->h_red) (void)hipHostFree(ctx->h_red);
-    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
-    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
-    if (ctx->ev_c0) (void)hipEventDestroy(ctx->ev_c0);
-    if (ctx->ev_c1) (void)hipEventDestroy(ctx->ev_c1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -530,11 +541,11 @@ int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t f
     return launch_tile(ctx, view, mrd, flags, d_counts, d_bytes, (hipStream_t)hip_stream);
 }
 
-int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
-                     int32_t *h_counts, uint8_t *h_bytes, mbk_stats *stats)
+// enqueue kernel + reduction + D2H of one tile on a slot's stream (no host synchronisation)
+static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                       int32_t *h_counts, uint8_t *h_bytes)
 {
-    if (!ctx || !view) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
-    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    if (sl.busy) return fail(ctx, MBK_ERR_INVALID, "slot still has a tile in flight: call mbk_wait first");
     const bool wc = (flags & MBK_WANT_COUNTS) != 0, wb = (flags & MBK_WANT_BYTES) != 0;
     if (wc && !h_counts) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_COUNTS with NULL counts pointer");
     if (wb && !h_bytes) return fail(ctx, MBK_ERR_INVALID, "MBK_WANT_BYTES with NULL bytes pointer");
@@ -542,55 +553,94 @@ int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t 
     int rc = validate_view(ctx, view, &dummy, (flags & MBK_PRECISION_F32) != 0);
     if (rc != MBK_OK) return rc;
     const size_t px = (size_t)view->ncols * view->nrows;
-    rc = ensure_buffers(ctx, px);
+    rc = ensure_buffers(ctx, sl, px);
     if (rc != MBK_OK) return rc;
     // counts are always produced on the device (they feed the stats reduction); only what the
     // caller asked for crosses PCIe.
     const uint32_t dev_flags = (flags & (MBK_KERNEL_MASK | MBK_PRECISION_F32)) | MBK_WANT_COUNTS | (wb ? MBK_WANT_BYTES : 0u);
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    rc = launch_tile(ctx, view, mrd, dev_flags, ctx->d_counts, ctx->d_bytes, ctx->stream);
+    MBK_HIP(ctx, hipEventRecord(sl.ev_k0, sl.stream));
+    rc = launch_tile(ctx, view, mrd, dev_flags, sl.d_counts, sl.d_bytes, sl.stream);
     if (rc != MBK_OK) return rc;
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-    rc = launch_reduce(ctx, ctx->d_counts, wb ? ctx->d_bytes : nullptr, px, mrd, ctx->stream);
+    MBK_HIP(ctx, hipEventRecord(sl.ev_k1, sl.stream));
+    rc = launch_reduce(ctx, sl, sl.d_counts, wb ? sl.d_bytes : nullptr, px, mrd, sl.stream);
     if (rc != MBK_OK) return rc;
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
-    if (wb) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, ctx->d_bytes, px, hipMemcpyDeviceToHost, ctx->stream));
-    if (wc)
-        MBK_HIP(ctx, hipMemcpyAsync(h_counts, ctx->d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                    ctx->stream));
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_c1, ctx->stream));
-    MBK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->last_px = wb ? px : 0;
+    MBK_HIP(ctx, hipEventRecord(sl.ev_c0, sl.stream));
+    if (wb) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, sl.d_bytes, px, hipMemcpyDeviceToHost, sl.stream));
+    if (wc) MBK_HIP(ctx, hipMemcpyAsync(h_counts, sl.d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost, sl.stream));
+    MBK_HIP(ctx, hipEventRecord(sl.ev_c1, sl.stream));
+    sl.busy = true;
+    sl.with_bytes = wb;
+    if (&sl == &ctx->s[0]) ctx->last_px = wb ? px : 0;
+    return MBK_OK;
+}
+
+static int wait_slot(mbk_ctx *ctx, Slot &sl, mbk_stats *stats)
+{
+    if (!sl.busy) return fail(ctx, MBK_ERR_INVALID, "nothing was submitted on this slot");
+    MBK_HIP(ctx, hipStreamSynchronize(sl.stream));
+    sl.busy = false;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev_k0, ctx->ev_k1));
-        MBK_HIP(ctx, hipEventElapsedTime(&stats->d2h_ms, ctx->ev_c0, ctx->ev_c1));
-        fill_stats_from_reduce(ctx, stats, wb);
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, sl.ev_k0, sl.ev_k1));
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->d2h_ms, sl.ev_c0, sl.ev_c1));
+        fill_stats_from_reduce(sl, stats, sl.with_bytes);
     }
     return MBK_OK;
 }
 
-int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_real,
-                  uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, mbk_stats *stats)
+static void datachunk_view(mbk_view *v, double sr, double si, double range)
+{
+    v->start_r = sr;
+    v->start_i = si;
+    v->range_r = range;
+    v->range_i = range;
+    v->width = v->height = MBK_CHUNK_DEFINITION;
+    v->col0 = v->row0 = 0;
+    v->ncols = v->nrows = MBK_CHUNK_DEFINITION;
+}
+
+int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                     int32_t *h_counts, uint8_t *h_bytes, mbk_stats *stats)
+{
+    if (!ctx || !view) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = submit_view(ctx, ctx->s[0], view, mrd, flags, h_counts, h_bytes);
+    if (rc != MBK_OK) return rc;
+    return wait_slot(ctx, ctx->s[0], stats);
+}
+
+int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
+                         uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts)
 {
     if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
+    if (slot < 0 || slot >= MBK_SLOTS) return fail(ctx, MBK_ERR_INVALID, "slot out of range");
     if (!h_bytes) return fail(ctx, MBK_ERR_INVALID, "h_bytes is NULL");
-    mbk_view v;
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
     double sr, si, range;
     int rc = mbk_datachunk_geometry(level, index_real, index_imag, &sr, &si, &range);
     if (rc != MBK_OK) {
         ctx->err = g_err;
         return rc;
     }
-    v.start_r = sr;
-    v.start_i = si;
-    v.range_r = range;
-    v.range_i = range;
-    v.width = v.height = MBK_CHUNK_DEFINITION;
-    v.col0 = v.row0 = 0;
-    v.ncols = v.nrows = MBK_CHUNK_DEFINITION;
-    const uint32_t flags = MBK_WANT_BYTES | (h_counts ? MBK_WANT_COUNTS : 0u);
-    return mbk_view_compute(ctx, &v, mrd, flags, h_counts, h_bytes, stats);
+    mbk_view v;
+    datachunk_view(&v, sr, si, range);
+    return submit_view(ctx, ctx->s[slot], &v, mrd, MBK_WANT_BYTES | (h_counts ? MBK_WANT_COUNTS : 0u), h_counts, h_bytes);
+}
+
+int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats)
+{
+    if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
+    if (slot < 0 || slot >= MBK_SLOTS) return fail(ctx, MBK_ERR_INVALID, "slot out of range");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    return wait_slot(ctx, ctx->s[slot], stats);
+}
+
+int mbk_datachunk(mbk_ctx *ctx, uint32_t level, uint32_t mrd, uint32_t index_real,
+                  uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, mbk_stats *stats)
+{
+    int rc = mbk_datachunk_submit(ctx, 0, level, mrd, index_real, index_imag, h_bytes, h_counts);
+    if (rc != MBK_OK) return rc;
+    return wait_slot(ctx, ctx->s[0], stats);
 }
 
 int mbk_view_launch_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
@@ -611,7 +661,7 @@ int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, ui
     int rc = validate_view(ctx, view, &dummy);
     if (rc != MBK_OK) return rc;
     const size_t px = (size_t)view->ncols * view->nrows;
-    rc = ensure_buffers(ctx, px);
+    rc = ensure_buffers(ctx, ctx->s[0], px);
     if (rc != MBK_OK) return rc;
     if (px > ctx->smooth_cap_px) {
         if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
@@ -620,25 +670,25 @@ int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, ui
         MBK_HIP(ctx, hipMalloc((void **)&ctx->d_smooth, px * sizeof(double)));
         ctx->smooth_cap_px = px;
     }
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    rc = launch_tile(ctx, view, mrd, (flags & MBK_KERNEL_MASK) | MBK_WANT_COUNTS, ctx->d_counts, nullptr,
-                     ctx->stream, ctx->d_smooth);
+    MBK_HIP(ctx, hipEventRecord(ctx->s[0].ev_k0, ctx->s[0].stream));
+    rc = launch_tile(ctx, view, mrd, (flags & MBK_KERNEL_MASK) | MBK_WANT_COUNTS, ctx->s[0].d_counts, nullptr,
+                     ctx->s[0].stream, ctx->d_smooth);
     if (rc != MBK_OK) return rc;
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-    rc = launch_reduce(ctx, ctx->d_counts, nullptr, px, mrd, ctx->stream);
+    MBK_HIP(ctx, hipEventRecord(ctx->s[0].ev_k1, ctx->s[0].stream));
+    rc = launch_reduce(ctx, ctx->s[0], ctx->s[0].d_counts, nullptr, px, mrd, ctx->s[0].stream);
     if (rc != MBK_OK) return rc;
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_c0, ctx->stream));
-    MBK_HIP(ctx, hipMemcpyAsync(h_smooth, ctx->d_smooth, px * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MBK_HIP(ctx, hipEventRecord(ctx->s[0].ev_c0, ctx->s[0].stream));
+    MBK_HIP(ctx, hipMemcpyAsync(h_smooth, ctx->d_smooth, px * sizeof(double), hipMemcpyDeviceToHost, ctx->s[0].stream));
     if (h_counts)
-        MBK_HIP(ctx, hipMemcpyAsync(h_counts, ctx->d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    MBK_HIP(ctx, hipEventRecord(ctx->ev_c1, ctx->stream));
-    MBK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        MBK_HIP(ctx, hipMemcpyAsync(h_counts, ctx->s[0].d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s[0].stream));
+    MBK_HIP(ctx, hipEventRecord(ctx->s[0].ev_c1, ctx->s[0].stream));
+    MBK_HIP(ctx, hipStreamSynchronize(ctx->s[0].stream));
     ctx->last_px = 0;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->ev_k0, ctx->ev_k1));
-        MBK_HIP(ctx, hipEventElapsedTime(&stats->d2h_ms, ctx->ev_c0, ctx->ev_c1));
-        fill_stats_from_reduce(ctx, stats, false);
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, ctx->s[0].ev_k0, ctx->s[0].ev_k1));
+        MBK_HIP(ctx, hipEventElapsedTime(&stats->d2h_ms, ctx->s[0].ev_c0, ctx->s[0].ev_c1));
+        fill_stats_from_reduce(ctx->s[0], stats, false);
     }
     return MBK_OK;
 }
@@ -669,8 +719,8 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
     unsigned long long *d_tot = (unsigned long long *)(ctx->d_rle + off_tot);
     uint32_t *d_start = (uint32_t *)(ctx->d_rle + off_start);
     uint8_t *d_val = ctx->d_rle + off_val, *d_out = ctx->d_rle + off_out;
-    hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(mbk::rle_count_kernel, dim3(nblocks), dim3(mbk::kRleBlock), 0, s, ctx->d_bytes, (uint64_t)n, d_cnt);
+    hipStream_t s = ctx->s[0].stream;
+    hipLaunchKernelGGL(mbk::rle_count_kernel, dim3(nblocks), dim3(mbk::kRleBlock), 0, s, ctx->s[0].d_bytes, (uint64_t)n, d_cnt);
     hipLaunchKernelGGL(mbk::rle_scan_kernel, dim3(1), dim3(1024), 0, s, d_cnt, nblocks, d_tot);
     MBK_HIP(ctx, hipGetLastError());
     unsigned long long runs = 0;
@@ -683,7 +733,7 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
     *size = use_rle ? rle_size : raw_size;
     if (cap < *size) return fail(ctx, MBK_ERR_INVALID, "output buffer too small for the serialised chunk");
     if (use_rle) {
-        hipLaunchKernelGGL(mbk::rle_scatter_kernel, dim3(nblocks), dim3(mbk::kRleBlock), 0, s, ctx->d_bytes,
+        hipLaunchKernelGGL(mbk::rle_scatter_kernel, dim3(nblocks), dim3(mbk::kRleBlock), 0, s, ctx->s[0].d_bytes,
                            (uint64_t)n, d_cnt, d_start, d_val);
         hipLaunchKernelGGL(mbk::rle_emit_kernel, dim3((uint32_t)((runs + 255) / 256)), dim3(256), 0, s, d_start,
                            d_val, (uint64_t)runs, (uint64_t)n, d_out);
@@ -691,7 +741,7 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
         MBK_HIP(ctx, hipMemcpyAsync(h_out, d_out, rle_size, hipMemcpyDeviceToHost, s));
     } else {
         h_out[0] = MBK_CODEC_RAW;
-        MBK_HIP(ctx, hipMemcpyAsync(h_out + 1, ctx->d_bytes, n, hipMemcpyDeviceToHost, s));
+        MBK_HIP(ctx, hipMemcpyAsync(h_out + 1, ctx->s[0].d_bytes, n, hipMemcpyDeviceToHost, s));
     }
     MBK_HIP(ctx, hipStreamSynchronize(s));
     return MBK_OK;
@@ -703,11 +753,11 @@ int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_
     if (!ctx || !d_counts || !stats) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
     MBK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    int rc = launch_reduce(ctx, d_counts, nullptr, n, mrd, s);
+    int rc = launch_reduce(ctx, ctx->s[0], d_counts, nullptr, n, mrd, s);
     if (rc != MBK_OK) return rc;
     MBK_HIP(ctx, hipStreamSynchronize(s));
     std::memset(stats, 0, sizeof(*stats));
-    fill_stats_from_reduce(ctx, stats, false);
+    fill_stats_from_reduce(ctx->s[0], stats, false);
     return MBK_OK;
 }
 

@@ -201,6 +201,19 @@ class MandelbrotDevice:
         self._check(st)
         return self._ser_buf[:size.value].tobytes(), int(codec.value)
 
+    def submit_datachunk(self, slot: int, level: int, mrd: int, index_real: int, index_imag: int,
+                         out_bytes: np.ndarray) -> None:
+        """Enqueue a tile on `slot` (0 or 1) and return at once; `out_bytes` (uint8[16777216], ideally from
+        pinned_empty) is valid after wait(slot).  Two slots = the D2H of one tile overlaps the next kernel."""
+        assert out_bytes.dtype == np.uint8 and out_bytes.size == L.MBK_CHUNK_BYTES and out_bytes.flags.c_contiguous
+        self._check(self._lib.mbk_datachunk_submit(self._h, slot, level, mrd, index_real, index_imag,
+                                                   out_bytes.ctypes.data, None))
+
+    def wait(self, slot: int) -> TileStats:
+        st = L.mbk_stats()
+        self._check(self._lib.mbk_wait(self._h, slot, C.byref(st)))
+        return _stats(st)
+
     def launch_view(self, view: View, mrd: int, *, d_counts: int = 0, d_bytes: int = 0,
                     stream: int = 0, window=None, kernel: str = "default", precision: str = "f64") -> None:
         """Asynchronous launch on raw DEVICE pointers (e.g. torch tensors' data_ptr()) on ``stream``

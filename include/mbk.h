@@ -167,6 +167,19 @@ int mbk_view_launch_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uin
 int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
                             int32_t *h_counts, double *h_smooth, mbk_stats *stats);
 
+/*
+ * Two tiles in flight per context ("double-buffered streams": the D2H of one tile overlaps the kernel
+ * of the next; each slot has its own HIP stream, events and device buffers).  mbk_datachunk_submit
+ * enqueues kernel + stats reduction + D2H for a tile on `slot` (0 .. MBK_SLOTS-1) and returns at once;
+ * mbk_wait blocks until that slot's tile is in h_bytes / h_counts (use pinned memory, mbk_host_alloc,
+ * or the copy is not asynchronous) and fills stats.  A slot holds one tile at a time.  Slot 0 is also
+ * what the synchronous calls use.  Same single-host-thread rule as everything else on a ctx.
+ */
+#define MBK_SLOTS 2
+int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
+                         uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts);
+int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats);
+
 /* Codec codes of DataChunkSerializer.cs (Raw :20, RLE :54). */
 #define MBK_CODEC_RAW 0x00u
 #define MBK_CODEC_RLE 0x01u

@@ -23,3 +23,15 @@ n = level * level
 print(f"level {level} mrd {mrd}: {n} tiles in {dt:.3f} s = {n/dt:.1f} tiles/s ({its/dt/1e9:.0f} G pixel-iter/s wall); "
       f"kernel ms mean {np.mean(ks):.3f} median {np.median(ks):.3f} max {np.max(ks):.3f} (sum {np.sum(ks)/1e3:.3f} s); "
       f"d2h ms mean {np.mean(ds):.3f}; Never {never} Immediate {imm} RLE-smaller {rle} of {n}")
+
+# the same level with two tiles in flight (mbk_datachunk_submit / mbk_wait): D2H of tile n overlaps kernel n+1
+pins = [dev.pinned_empty((16777216,), np.uint8) for _ in range(2)]
+tiles = [(ir, ii) for ir in range(level) for ii in range(level)]
+t0 = time.perf_counter()
+dev.submit_datachunk(0, level, mrd, *tiles[0], pins[0])
+for i in range(1, len(tiles) + 1):
+    if i < len(tiles):
+        dev.submit_datachunk(i % 2, level, mrd, *tiles[i], pins[i % 2])
+    dev.wait((i - 1) % 2)
+dt2 = time.perf_counter() - t0
+print(f"two slots in flight: {n} tiles in {dt2:.3f} s = {n/dt2:.1f} tiles/s")

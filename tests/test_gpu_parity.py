@@ -279,3 +279,23 @@ def test_fuzz_many_small_views(gpu, oracle, precision):
                                     window=window, precision=precision)
         assert np.array_equal(c, oc), (k, view, mrd, window, int((c != oc).sum()))
         assert np.array_equal(b, ob) and st.pixel_iterations == total, (k, view, mrd)
+
+
+def test_two_tiles_in_flight_submit_wait(gpu, golden):
+    """mbk_datachunk_submit / mbk_wait: two slots, results identical to the synchronous path (goldens)."""
+    from distributedmandelbrot_amd import MbkError
+    bufs = [gpu.pinned_empty((16777216,), np.uint8) for _ in range(2)]
+    keys = ["4_256_0_0", "10_1024_0_5", "4_256_1_2", "4_256_0_0"]
+    params = [tuple(int(x) for x in golden[f"full/{k}/params"]) for k in keys]
+    gpu.submit_datachunk(0, *params[0], bufs[0])
+    with pytest.raises(MbkError):
+        gpu.submit_datachunk(0, *params[1], bufs[0])              # slot busy
+    for i in range(1, len(params) + 1):                           # software pipeline: submit i, wait i-1
+        if i < len(params):
+            gpu.submit_datachunk(i % 2, *params[i], bufs[i % 2])
+        st = gpu.wait((i - 1) % 2)
+        got = hashlib.sha256(bufs[(i - 1) % 2].tobytes()).hexdigest()
+        assert got == str(golden[f"full/{keys[i - 1]}/bytes_sha256"]), keys[i - 1]
+        assert st.never_pixels == int(golden[f"full/{keys[i - 1]}/zeros"])
+    with pytest.raises(MbkError):
+        gpu.wait(0)                                               # nothing in flight
