@@ -131,6 +131,9 @@ FULL = [
     (4, 256, 0, 0),        # all exterior: cheap under CPython
     (10, 1024, 0, 5),      # [-2,-1.6] x [0,0.4]: row 0 is the real-axis antenna (never escapes), slow escapes above it
     (4, 256, 1, 2),        # [-1,0] x [0,1]: cardioid + period-2 bulb + boundary filaments (minutes under CPython)
+    (1, 256, 0, 0),        # the whole [-2,2]^2 image (SURVEY.md section 4 KAT list)
+    (10, 1024, 3, 5),      # [-0.8,-0.4] x [0,0.4]: bulb boundary, ~half in-set (SURVEY KAT list; ~10 min)
+    (20, 1024, 7, 9),      # [-0.6,-0.4] x [-0.2,0]: inside the cardioid, every pixel runs 1023 steps (~15 min)
 ]
 if os.environ.get("GOLDEN_SKIP_EXPENSIVE"):
     FULL = FULL[:2]
