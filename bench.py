@@ -144,12 +144,22 @@ def main():
     sr, si, rng, width, height, mrd, desc = workload
     npix = width * height
 
+    backend = None
     if world > 1:
         if fake:
+            backend = "gloo"
             dist.init_process_group(backend="gloo")
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            try:   # RCCL: only the barrier and two scalar reductions use it -- the tiles need no collective
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                backend = "nccl"
+            except Exception as e:  # keep the scaling run alive if RCCL cannot come up on this node
+                print(f"[bench] nccl init failed ({e!r}); using gloo for the barrier/reductions", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group(backend="gloo")
+                backend = "gloo"
 
     def barrier():
         if world > 1:
@@ -238,7 +248,7 @@ def main():
 
     # max elapsed over ranks, total work over ranks
     if world > 1:
-        dev_t = "cpu" if fake else f"cuda:{local_rank}"
+        dev_t = "cpu" if backend == "gloo" else f"cuda:{local_rank}"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_max = float(t.item())
@@ -274,7 +284,7 @@ def main():
                                    "written to resident HBM", "kernel": args.kernel,
                        "pixels_per_step_per_gpu": npix, "pixel_iterations_per_step_per_gpu": iters_per_step,
                        "never_escaped_pixels": never, "parallelism": f"{world} independent tile queue(s), no collective",
-                       "streams_per_gpu": max(1, args.streams), "shard": args.shard,
+                       "streams_per_gpu": max(1, args.streams), "shard": args.shard, "control_backend": backend,
                        "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus,
                        "clock_mhz": mhz},
             "roofline": {
