@@ -98,3 +98,24 @@ def test_bench_distributed_path_gloo_world2():
     # fake backend: every rank reports 1e9 pixel-iterations per step -> aggregate = 2e9 * steps / time
     assert rec["config"]["fake_backend"] is True
     assert abs(rec["value"] - 2 * 1.0 * 3 / (rec["ms_per_step"] * 3 / 1e3)) / rec["value"] < 1e-6
+
+
+def test_bench_json_contract_single_rank_fake():
+    """The one-line JSON of bench.py carries every field the round contract names (checked on the CPU
+    with the stub backend; the real numbers come from the GPU run)."""
+    env = dict(os.environ, MBK_BENCH_FAKE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["vs_baseline"] is None
+    assert rec["unit"] == "G pixel-iterations/s" and rec["dtype"] == "f64" and "workload" in rec["config"]
+    assert "model" not in rec["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rec["roofline"], key
+    assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-12
