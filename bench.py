@@ -101,6 +101,12 @@ def cpu_baseline(workload, precision="f64"):
     rec = {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
            "sample": sample + f", mrd {mrd}, C oracle gcc -O2 -ffp-contract=off, OpenMP dynamic rows",
            "seconds": dt}
+    # one thread, on every 16th 8-row band (the all-core figure above divided by `cores` hides the SMT/boost effects)
+    t0 = time.perf_counter()
+    tot1 = sum(o.view(sr, si, rng, rng, w, h, mrd, window=(0, r, w, 8), want_counts=False, want_bytes=False,
+                      nthreads=1, precision=precision)[2] for r in range(0, h, 128))
+    dt1 = time.perf_counter() - t0
+    rec["single_thread"] = {"value": tot1 / dt1 / 1e9, "seconds": dt1, "sample": f"every 16th 8-row band ({h // 16} rows)"}
     if precision == "f64" and stride == 1 and o.have_avx512():
         # best-effort CPU: the same strict arithmetic 8 pixels at a time in AVX-512 (no fmadd), same threads
         t0 = time.perf_counter()

@@ -30,16 +30,21 @@ def test_constants_match_reference():
     assert (worker.MIN_AXIS, worker.MAX_AXIS) == (-2, 2)
 
 
-def test_single_tile_roundtrip_with_oracle_compute(oracle):
+def test_single_tile_roundtrip_with_oracle_compute(oracle, golden):
+    """BASELINE cfg1 at the wire level: DataChunk (level 1, 0, 0), mrd 256, one worker, through
+    the Distributer protocol; the bytes that arrive equal the tile the reference's own process_workload
+    produced (golden SHA-256)."""
+    import hashlib
+
     def oracle_compute(level, mrd, ir, ii):
         return oracle.datachunk(level, mrd, ir, ii, want_counts=False)[1].ravel()
 
-    with FakeDistributer([(1, 64)]) as srv:
+    with FakeDistributer([(1, 256)]) as srv:
         assert worker.do_workload_single("127.0.0.1", srv.port, compute=oracle_compute, log=QUIET) is True
         assert worker.do_workload_single("127.0.0.1", srv.port, compute=oracle_compute, log=QUIET) is False
         (w, data), = srv.completed.items()
-        assert w == (1, 64, 0, 0)
-        assert np.array_equal(data, oracle_compute(1, 64, 0, 0))
+        assert w == (1, 256, 0, 0)
+        assert hashlib.sha256(data.tobytes()).hexdigest() == str(golden["full/1_256_0_0/bytes_sha256"])
         assert not srv.leases
 
 
