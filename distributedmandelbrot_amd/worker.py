@@ -77,8 +77,21 @@ def _process_workload_pinned(level: int, mrd: int, index_real: int, index_imag: 
     """Same tile, but DMA'd straight into one reused pinned buffer (valid until the next call): what
     do_workload_single uses, since it sends the bytes before asking for the next tile."""
     dev = _get_default_device()
-    out, _, _ = dev.datachunk(level, mrd, index_real, index_imag, out_bytes=_default_pinned)
+    out, _, st = dev.datachunk(level, mrd, index_real, index_imag, out_bytes=_default_pinned)
+    _last_stats["default"] = st
     return out
+
+
+_last_stats = {}  # device label -> TileStats of the last tile (the reference has no metrics at all; SURVEY.md 5)
+
+
+def describe_stats(st) -> str:
+    """One log line for a finished tile: kernel time, throughput, and what the server will do with it."""
+    kind = "Never" if st.all_bytes_zero else "Immediate" if st.all_bytes_one else \
+        ("RLE" if 1 + 5 * st.rle_runs < 1 + CHUNK_BYTES else "Raw")
+    rate = st.pixel_iterations / st.kernel_ms / 1e6 if st.kernel_ms > 0 else 0.0
+    return (f"kernel {st.kernel_ms:.3f} ms, D2H {st.d2h_ms:.3f} ms, {st.pixel_iterations / 1e9:.2f} G pixel-iterations "
+            f"({rate:.0f} G/s), {st.never_pixels} in-set pixels, stored as {kind}")
 
 
 def _recv_exact(sock: socket.socket, n: int) -> bytes:
@@ -153,6 +166,8 @@ def do_workload_single(addr: str, port: int, compute: Optional[ComputeFn] = None
     t0 = time.perf_counter()
     out = (compute or _process_workload_pinned)(*workload)
     log("Calculation complete (%.1f ms)" % ((time.perf_counter() - t0) * 1e3))
+    if compute is None and "default" in _last_stats:
+        log(describe_stats(_last_stats["default"]))
     if submit_workload(addr, port, workload, out):
         log("Response accepted")
         log("Sent response")
@@ -180,7 +195,8 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
         pinned = dev.pinned_empty((CHUNK_BYTES,), np.uint8)
 
         def compute(level, mrd, ir, ii):
-            out, _, _ = dev.datachunk(level, mrd, ir, ii, out_bytes=pinned)
+            out, _, st = dev.datachunk(level, mrd, ir, ii, out_bytes=pinned)
+            log(f"[gpu{dev_index}]", describe_stats(st))
             return out
         return compute
 
