@@ -60,8 +60,12 @@ VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.25, "group": 6.25, "refill": 6.25, "as
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, ~0.3-6 s of GPU time)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: per workload)")
+    ap.add_argument("--ramp-ms", type=float, default=150.0,
+                    help="untimed clock pre-conditioning before the warm-up steps: the same launches are repeated "
+                         "for this long so that DVFS has left its idle state (an MI355X needs ~50-100 ms of load to "
+                         "reach its sustained clock; a 0.6 ms tile measured cold reads 15-20 %% low). 0 disables.")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="default")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
@@ -131,8 +135,18 @@ def pmc_traffic(workload, kernel):
         return None
 
 
+# default (steps, warmup) per workload: enough launches for a steady clock, a few seconds at most
+DEFAULT_STEPS = {"cfg1": (400, 50), "cfg2": (400, 50), "chunk_l1": (400, 50), "inset": (60, 8), "exterior": (400, 50),
+                 "cfg3": (20, 3), "cfg4": (3, 1)}
+
+
 def main():
     args = parse_args()
+    d_steps, d_warm = DEFAULT_STEPS.get(args.workload, (20, 3))
+    if args.steps is None:
+        args.steps = d_steps
+    if args.warmup is None:
+        args.warmup = d_warm
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,6 +229,11 @@ def main():
         def sync():
             torch.cuda.synchronize()
 
+    if not fake and args.ramp_ms > 0:   # clock pre-conditioning (untimed, see --ramp-ms)
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            launch()
+            sync()
     for _ in range(args.warmup):
         launch()
     sync()
@@ -290,7 +309,7 @@ def main():
                                    "written to resident HBM", "kernel": args.kernel,
                        "pixels_per_step_per_gpu": npix, "pixel_iterations_per_step_per_gpu": iters_per_step,
                        "never_escaped_pixels": never, "parallelism": f"{world} independent tile queue(s), no collective",
-                       "streams_per_gpu": max(1, args.streams), "shard": args.shard, "control_backend": backend,
+                       "streams_per_gpu": max(1, args.streams), "shard": args.shard, "control_backend": backend, "clock_ramp_ms": 0.0 if fake else args.ramp_ms,
                        "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus,
                        "clock_mhz": mhz},
             "roofline": {
