@@ -11,6 +11,10 @@ For N > 1 the driver launches one rank per GPU (torch.distributed.run); tiles ar
 every rank computes its own tile with no data-path collective ("weak" scaling); the only
 communication is the barrier and the max-over-ranks of the elapsed time.
 
+Before the W warm-up steps the clock is pre-conditioned for --ramp-ms (150 ms) with untimed launches of
+the same workload: an idle MI355X needs 50-100 ms of load to reach its sustained clock, and a 0.6 ms tile
+measured cold reads 15-20 % low.
+
 Prints ONE JSON line on rank 0.  `value` = whole-job G pixel-iterations/s where a pixel's iterations
 are count if count > 0 else mrd-1, summed from the kernel's own output.
 `roofline`: the path is bound by the fp64 vector-ALU issue rate (not HBM, not MFMA -- FMA contraction
