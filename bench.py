@@ -9,7 +9,11 @@ kernel generates its coordinates itself and writes int32 escape indices to a res
 ("cfg2"): 4096x4096 samples of the full set (centre -0.5+0i, span 3.0), max_iter (mrd) = 1000, fp64.
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); tiles are independent, so
 every rank computes its own tile with no data-path collective ("weak" scaling); the only
-communication is the barrier and the max-over-ranks of the elapsed time.
+communication is the barrier and the max-over-ranks of the elapsed time, on gloo (CPU tensors) -- there
+is no RCCL anywhere (`--control nccl` exists to A/B that choice).  `--shard bands` is the strong-scaling
+form BASELINE cfg3 asks for: ONE view per step, cut into >= 16 row bands per GPU which the ranks pull
+from a cursor in shared memory (distributedmandelbrot_amd.sharding.SharedCursor; dynamic, because band
+cost varies >100x), two bands in flight per GPU.
 
 Before the W warm-up steps the clock is pre-conditioned for --ramp-ms (150 ms) with untimed launches of
 the same workload: an idle MI355X needs 50-100 ms of load to reach its sustained clock, and a 0.6 ms tile
@@ -18,13 +22,14 @@ measured cold reads 15-20 % low.
 Prints ONE JSON line on rank 0.  `value` = whole-job G pixel-iterations/s where a pixel's iterations
 are count if count > 0 else mrd-1, summed from the kernel's own output.
 `roofline`: the path is bound by the fp64 vector-ALU issue rate (not HBM, not MFMA -- FMA contraction
-is forbidden by bit-exactness): achieved = 8 algorithmic flops per pixel-iteration / average kernel
+is forbidden by bit-exactness): achieved = 8 algorithmic flops per pixel-iteration / average
 launch duration (HIP events on the launch stream); peak = CUs x 4 SIMD x 16 fp64 lanes x 2 flop x
 clock (78.6 TFLOP/s on MI355X).  Under parity the default kernel needs 6.25 fp64-rate VALU issue
 slots per 8 flops (6 arithmetic ops per step + one add and one compare per 8 steps), so the flops
 fraction cannot exceed 8/12.5 = 0.64; `valu_slot_util` (= issue slots actually spent per
 pixel-iteration over the 39.3 T lane-op/s issue peak at 2.4 GHz) is the "how close to the metal"
-figure.
+figure.  `traffic` is HBM bytes per launch from separate `rocprofv3 --pmc` passes of this same command
+(committed under profiles/, see `traffic_source`); counters cannot be read from inside the run.
 `cpu_baseline`: the strict-IEEE C oracle (oracle/, kind "port": the reference has no CPU
 implementation and its numba path cannot run here) on the host cores, rank 0, N = 1 only.
 """
@@ -53,12 +58,23 @@ WORKLOADS = {
     "exterior": (-2.0, -2.0, 1.0, 4096, 4096, 1000, "DataChunk (4,0,0): every pixel escapes within 3 steps"),
     # BASELINE configs[3]: centre/span are not given there; SURVEY 8(d) proposes centre -0.745+0.11i, span 0.02
     "cfg4": (-0.755, 0.10, 0.02, 16384, 16384, 50000,
-             "16384x16384 seahorse valley (centre -0.745+0.11i, span 0.02), mrd 50000 -- use --precision f32"),
+             "16384x16384 seahorse valley (centre -0.745+0.11i, span 0.02), mrd 50000, fp32 kernel variant"),
+    # BASELINE configs[4]: no view given; the full-set view of cfg2 with the continuous value as output
+    "cfg5": (-2.0, -1.5, 3.0, 4096, 4096, 5000,
+             "4096x4096 full set (centre -0.5+0i, span 3.0), mrd 5000, continuous (smooth) colouring: float64 nu + int32 count per pixel"),
 }
+DEFAULT_PRECISION = {"cfg4": "f32"}
+SMOOTH_WORKLOADS = {"cfg5"}
 FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
 # fp64-rate VALU issue slots each kernel spends per pixel-iteration (v_cmp costs a full slot on gfx950):
 #   per-step test: 3 mul + 3 add + 1 fma + 1 v_cmp = 8;  grouped test (default): 6 + 2 per 8 steps = 6.25
-VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.25, "group": 6.25, "refill": 6.25, "asm": 8.0, "simple": 8.0}
+VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.25, "scan": 6.25, "group": 6.25, "refill": 6.25, "asm": 8.0, "simple": 8.0}
+# default (steps, warmup) per workload: enough launches for a steady clock, a few seconds at most
+DEFAULT_STEPS = {"cfg1": (400, 50), "cfg2": (400, 50), "chunk_l1": (400, 50), "inset": (60, 8), "exterior": (400, 50),
+                 "cfg3": (20, 3), "cfg4": (3, 1), "cfg5": (40, 5)}
+# CPU baseline sample: every `stride`-th 8-row band, sized for ~10-30 CPU-seconds on >= 64 host threads
+CPU_SAMPLE_STRIDE = {"cfg4": 256}
+PMC_SUMMARIES = [("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
 
 
 def parse_args():
@@ -72,27 +88,40 @@ def parse_args():
                          "reach its sustained clock; a 0.6 ms tile measured cold reads 15-20 %% low). 0 disables.")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="default")
-    ap.add_argument("--precision", default="f64", choices=["f64", "f32"],
-                    help="f32 = BASELINE cfg4's fp32 kernel variant (not in the reference)")
+    ap.add_argument("--precision", default=None, choices=["f64", "f32"],
+                    help="f32 = BASELINE cfg4's fp32 kernel variant (not in the reference); default f64, cfg4: f32")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning option (include/mbk.h enum mbk_option), e.g. --opt scan_steps=32; repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "bands"],
                     help="tiles (default): every rank computes its own tile per step (weak scaling). bands: ONE "
-                         "view per step is split into row bands (4 per rank) interleaved over the ranks (strong scaling; "
-                         "how BASELINE cfg3 shards an image over 8 GPUs)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="tiles in flight per GPU: steps are issued round-robin on this many HIP streams "
-                         "(1 = the contract's serial steps; 2 lets the next tile fill the drain of the last)")
+                         "view per step, cut into >= 16 row bands per GPU that the ranks pull from a shared-memory "
+                         "cursor (strong scaling; how BASELINE cfg3 shards an image over 8 GPUs)")
+    ap.add_argument("--band-rows", type=int, default=0, help="rows per band for --shard bands (default: height / (16 N), >= 8)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="tiles (or bands) in flight per GPU (default 1 for tiles = the contract's serial steps, 2 for bands)")
+    ap.add_argument("--control", default="gloo", choices=["gloo", "nccl"],
+                    help="backend of the barrier / timing reductions for N > 1 (no data-path collective exists)")
     return ap.parse_args()
 
 
-def cpu_baseline(workload, precision="f64"):
+def cpu_baseline(name, workload, precision="f64"):
     """Time the C oracle (oracle/mandel_oracle.c, -ffp-contract=off) on the host cores."""
     from oracle.oracle import COracle
     sr, si, rng, w, h, mrd, _ = workload
     o = COracle()
     cores = o.max_threads()
+    if name in SMOOTH_WORKLOADS:
+        import numpy as np
+        t0 = time.perf_counter()
+        _, counts = o.view_smooth(sr, si, rng, rng, w, h, mrd)
+        dt = time.perf_counter() - t0
+        total = int(np.where(counts > 0, counts, mrd - 1).astype(np.int64).sum())
+        return {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
+                "sample": f"the whole {w}x{h} tile, mrd {mrd}, continuous value + count per pixel (mbo_view_smooth), "
+                          "C oracle gcc -O2 -ffp-contract=off, OpenMP dynamic rows", "seconds": dt}
     # bounded sample: every `stride`-th row band of 8 rows, sized for roughly 10-30 CPU-seconds
-    stride = 1 if cores >= 4 else 4
+    stride = CPU_SAMPLE_STRIDE.get(name, 1 if cores >= 4 else 4)
     bands = [(0, r, w, 8) for r in range(0, h, 8 * stride)]
     t0 = time.perf_counter()
     total = 0
@@ -109,6 +138,8 @@ def cpu_baseline(workload, precision="f64"):
     rec = {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
            "sample": sample + f", mrd {mrd}, C oracle gcc -O2 -ffp-contract=off, OpenMP dynamic rows",
            "seconds": dt}
+    if name in ("cfg3", "cfg4"):
+        return rec       # one sample is already ~10 s of CPU
     # one thread, on every 16th 8-row band (the all-core figure above divided by `cores` hides the SMT/boost effects)
     t0 = time.perf_counter()
     tot1 = sum(o.view(sr, si, rng, rng, w, h, mrd, window=(0, r, w, 8), want_counts=False, want_bytes=False,
@@ -125,23 +156,21 @@ def cpu_baseline(workload, precision="f64"):
 
 
 def pmc_traffic(workload, kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass of this same command
-    (profiles/r01/cfg2_default_pmc_summary.json: WRITE_SIZE and FETCH_SIZE are in KiB; FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None for un-profiled combinations -- PMC
-    counters cannot be collected from inside the timed run itself."""
-    if workload != "cfg2" or kernel not in ("default", "group"):
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "cfg2_default_pmc_summary.json")) as f:
-            pmc = json.load(f)
-        return int(pmc["WRITE_SIZE"]["mean"] * 1024 + 2 * pmc["FETCH_SIZE"]["mean"] * 1024)
-    except Exception:
-        return None
-
-
-# default (steps, warmup) per workload: enough launches for a steady clock, a few seconds at most
-DEFAULT_STEPS = {"cfg1": (400, 50), "cfg2": (400, 50), "chunk_l1": (400, 50), "inset": (60, 8), "exterior": (400, 50),
-                 "cfg3": (20, 3), "cfg4": (3, 1)}
+    """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same command:
+    WRITE_SIZE and FETCH_SIZE are in KiB, each collected in its own pass; FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950.  (None, None) for un-profiled combinations."""
+    if workload != "cfg2" or kernel not in ("default", "scan", "group"):
+        return None, None
+    for rnd, fname in PMC_SUMMARIES:
+        path = os.path.join(ROOT, "profiles", rnd, fname)
+        try:
+            with open(path) as f:
+                pmc = json.load(f)
+            nbytes = int(pmc["WRITE_SIZE"]["mean"] * 1024 + 2 * pmc["FETCH_SIZE"]["mean"] * 1024)
+            return nbytes, f"profiles/{rnd}/{fname}: separate rocprofv3 --pmc passes of this command, not counters of this run"
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -151,6 +180,12 @@ def main():
         args.steps = d_steps
     if args.warmup is None:
         args.warmup = d_warm
+    if args.precision is None:
+        args.precision = DEFAULT_PRECISION.get(args.workload, "f64")
+    smooth = args.workload in SMOOTH_WORKLOADS
+    bands_mode = args.shard == "bands"
+    if args.streams is None:
+        args.streams = 2 if bands_mode else 1
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,6 +195,12 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if smooth and (bands_mode or args.precision != "f64"):
+        raise SystemExit("cfg5 (smooth colouring) runs with --shard tiles in fp64")
+    options = {}
+    for item in args.opt:
+        k, _, v = item.partition("=")
+        options[k] = int(v)
 
     import torch
     import torch.distributed as dist
@@ -170,134 +211,194 @@ def main():
 
     backend = None
     if world > 1:
-        if fake:
-            backend = "gloo"
+        if fake or args.control == "gloo":
+            backend = "gloo"     # barrier + two scalar reductions on CPU tensors: nothing here needs RCCL
             dist.init_process_group(backend="gloo")
         else:
             torch.cuda.set_device(local_rank)
-            try:   # RCCL: only the barrier and two scalar reductions use it -- the tiles need no collective
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-                backend = "nccl"
-            except Exception as e:  # keep the scaling run alive if RCCL cannot come up on this node
-                print(f"[bench] nccl init failed ({e!r}); using gloo for the barrier/reductions", file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group(backend="gloo")
-                backend = "gloo"
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            backend = "nccl"
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    nstreams = max(1, args.streams)
+    band_rows = args.band_rows or max(8, height // (16 * world))
+    band_rows = max(8, (band_rows // 8) * 8)
+    from distributedmandelbrot_amd.sharding import SharedCursor, make_bands
+    bands = make_bands(height, band_rows) if bands_mode else None
+    cursor = None
+    if bands_mode:
+        cname = f"{os.environ.get('MASTER_PORT', 'solo')}_{os.environ.get('TORCHELASTIC_RUN_ID', os.getppid())}"
+        if rank == 0:
+            cursor = SharedCursor(cname, create=True)
+        barrier()
+        if rank != 0:
+            cursor = SharedCursor(cname, create=False)
+
     if fake:
         dev = None
         device_info = {"name": "fake", "compute_units": 256, "clock_mhz": 2400}
+        streams = [None] * nstreams
 
-        def launch():
+        def launch_tile(i):
             time.sleep(0.001)
 
+        def launch_band(i, bnd):
+            time.sleep(0.0002 * (1 + bnd.index % 3))
+
         def sync():
+            pass
+
+        def slot_wait(i):
             pass
     else:
         from distributedmandelbrot_amd import MandelbrotDevice, View
         torch.cuda.set_device(local_rank)
         dev = MandelbrotDevice(local_rank)   # raises loudly without the HIP library / a gfx950 GPU
+        for k, v in options.items():
+            dev.set_option(k, v)
         device_info = dev.info()
         view = View(sr, si, rng, rng, width, height)
-        nstreams = max(1, args.streams)
-        d_counts_all = [torch.empty(npix, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(nstreams)]
-        d_counts = d_counts_all[0]
+        nbuf = 1 if bands_mode else nstreams
+        d_counts_all = [torch.empty(npix, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(nbuf)]
+        d_smooth_all = [torch.empty(npix, dtype=torch.float64, device=f"cuda:{local_rank}") for _ in range(nbuf)] if smooth else None
         streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
-        stream = streams[0]
-        turn = [0]
+        slot_events = [None] * nstreams
 
-        from distributedmandelbrot_amd.sharding import make_bands, rank_bands
-        band_rows = max(128, height // (4 * world))   # 4 interleaved slabs per rank: balance vs per-launch drain
-        my_bands = rank_bands(make_bands(height, band_rows), rank, world) if args.shard == "bands" else None
-
-        def launch():
-            i = turn[0] % nstreams
-            turn[0] += 1
-            if my_bands is None:
+        def launch_tile(i):
+            if smooth:
+                dev.launch_view_smooth(view, mrd, d_smooth=d_smooth_all[i].data_ptr(), d_counts=d_counts_all[i].data_ptr(),
+                                       stream=streams[i].cuda_stream, kernel=args.kernel)
+            else:
                 dev.launch_view(view, mrd, d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
                                 kernel=args.kernel, precision=args.precision)
-            else:  # this rank's row bands of the shared view, each written at its place in the image;
-                # bands go round-robin over the streams so that one band's drain overlaps the next band
-                for j, bnd in enumerate(my_bands):
-                    dev.launch_view(view, mrd, window=(0, bnd.row0, width, bnd.nrows),
-                                    d_counts=d_counts_all[0].data_ptr() + 4 * bnd.row0 * width,
-                                    stream=streams[j % nstreams].cuda_stream, kernel=args.kernel,
-                                    precision=args.precision)
-            return streams[i]
+
+        def launch_band(i, bnd):   # a row band of the shared view, written at its place in this rank's image
+            dev.launch_view(view, mrd, window=(0, bnd.row0, width, bnd.nrows),
+                            d_counts=d_counts_all[0].data_ptr() + 4 * bnd.row0 * width,
+                            stream=streams[i].cuda_stream, kernel=args.kernel, precision=args.precision)
+            ev = torch.cuda.Event()
+            ev.record(streams[i])
+            slot_events[i] = ev
+
+        def slot_wait(i):          # back-pressure: one band in flight per slot, or a rank would drain the cursor
+            if slot_events[i] is not None:
+                slot_events[i].synchronize()
+                slot_events[i] = None
 
         def sync():
             torch.cuda.synchronize()
 
-    if not fake and args.ramp_ms > 0:   # clock pre-conditioning (untimed, see --ramp-ms)
+    turn = [0]
+    my_tickets = []
+
+    def run_steps(nsteps, events=None):
+        """tiles: nsteps launches round-robin over the streams.  bands: pull tickets until nsteps images are done."""
+        if not bands_mode:
+            for _ in range(nsteps):
+                i = turn[0] % nstreams
+                turn[0] += 1
+                if events is not None and not fake:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(streams[i])
+                    launch_tile(i)
+                    e1.record(streams[i])
+                    events.append((e0, e1))
+                else:
+                    launch_tile(i)
+            return
+        limit = nsteps * len(bands)
+        while True:
+            i = turn[0] % nstreams
+            slot_wait(i)
+            t = cursor.next()
+            if t >= limit:
+                break
+            turn[0] += 1
+            if events is not None:
+                my_tickets.append(t)
+            launch_band(i, bands[t % len(bands)])
+
+    if not fake and args.ramp_ms > 0 and not bands_mode:   # clock pre-conditioning (untimed, see --ramp-ms)
         t_ramp = time.perf_counter()
         while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-            launch()
+            launch_tile(0)
             sync()
-    for _ in range(args.warmup):
-        launch()
+    run_steps(args.warmup if not bands_mode else max(args.warmup, 1))
     sync()
     barrier()
+    if bands_mode:
+        if rank == 0:
+            cursor.reset(0)
+        barrier()
     events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if not fake:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            st_ = streams[turn[0] % nstreams]
-            e0.record(st_)
-            launch()
-            e1.record(st_)
-            events.append((e0, e1))
-        else:
-            launch()
+    run_steps(args.steps, events)
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
 
+    never = 0
     if fake:
         iters_per_step = 10 ** 9
         kernel_ms = [elapsed / args.steps * 1e3] * args.steps
-        never = 0
     else:
-        if my_bands is None:
-            st = dev.reduce_counts(d_counts.data_ptr(), npix, mrd, stream=stream.cuda_stream)
-            iters_per_step, never = st.pixel_iterations, st.never_pixels
-        else:
-            iters_per_step = never = 0
-            for bnd in my_bands:
-                st = dev.reduce_counts(d_counts.data_ptr() + 4 * bnd.row0 * width, bnd.nrows * width, mrd,
-                                       stream=stream.cuda_stream)
-                iters_per_step += st.pixel_iterations
-                never += st.never_pixels
-        kernel_ms = [a.elapsed_time(b) for a, b in events]
+        if bands_mode:      # work per step = the whole image, measured once (untimed) on every rank's own GPU
+            launch_tile(0)
+            sync()
+        st = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
+        iters_per_step, never = st.pixel_iterations, st.never_pixels
+        kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
 
-    # max elapsed over ranks, total work over ranks
+    bands_once = None
     if world > 1:
-        dev_t = "cpu" if backend == "gloo" else f"cuda:{local_rank}"
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_max = float(t.item())
-        w_ = torch.tensor([float(iters_per_step)], dtype=torch.float64, device=dev_t)
-        dist.all_reduce(w_, op=dist.ReduceOp.SUM)
-        iters_all = float(w_.item())
+        if bands_mode:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, my_tickets)
+            allt = sorted(x for g in gathered for x in g)
+            bands_once = allt == list(range(args.steps * len(bands)))
+            per_rank_bands = [len(g) for g in gathered]
     else:
-        elapsed_max, iters_all = elapsed, float(iters_per_step)
+        elapsed_max = elapsed
+        if bands_mode:
+            bands_once = sorted(my_tickets) == list(range(args.steps * len(bands)))
+            per_rank_bands = [len(my_tickets)]
+    # weak scaling: every rank did the same tile; strong scaling: the ranks shared one image per step
+    iters_all = float(iters_per_step) * (1 if bands_mode else world)
 
     if rank == 0:
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+        if bands_mode:      # per-GPU average time per image, idle time included
+            avg_kernel_s = elapsed_max / args.steps
         cus, mhz = device_info["compute_units"], device_info["clock_mhz"]
         lanes_per_clk = 16 if args.precision == "f64" else 32  # per SIMD: fp64 16, fp32 32 (SIMD-32)
         peak_lane_ops = cus * 4 * lanes_per_clk * mhz * 1e6    # VALU lane-ops/s of that type
         peak_tflops = peak_lane_ops * 2 / 1e12                 # FMA = 2 flop -> 78.6 (fp64) / 157.3 (fp32)
-        achieved_tflops = FLOPS_PER_PIXEL_ITER * iters_per_step / avg_kernel_s / 1e12
+        per_gpu_iters = iters_per_step / (world if bands_mode else 1)
+        achieved_tflops = FLOPS_PER_PIXEL_ITER * per_gpu_iters / avg_kernel_s / 1e12
         slots = VALU_SLOTS_PER_PIXEL_ITER.get(args.kernel, 8.0)
-        out_bytes = npix * 4
+        out_bytes = npix * (12 if smooth else 4)
+        traffic, traffic_source = pmc_traffic(args.workload, args.kernel) if args.precision == "f64" and not options else (None, None)
+        metric = "G pixel-iterations/s on 4096^2 tile, max_iter=1000 fp64"
+        cfg = {"workload": f"{args.workload}: {desc}; " + (
+                   f"one image per step cut into {len(bands)} row bands of {band_rows} rows pulled from a shared cursor"
+                   if bands_mode else "one tile per GPU per step") + ", int32 counts written to resident HBM",
+               "kernel": args.kernel, "options": options,
+               "pixels_per_step": npix * (1 if bands_mode else world), "pixel_iterations_per_step_per_gpu": per_gpu_iters,
+               "never_escaped_pixels": never, "parallelism": f"{world} independent work queue(s), no collective",
+               "streams_per_gpu": nstreams, "shard": args.shard, "control_backend": backend,
+               "clock_ramp_ms": 0.0 if fake or bands_mode else args.ramp_ms,
+               "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz}
+        if bands_mode:
+            cfg.update({"bands_per_image": len(bands), "band_rows": band_rows, "bands_exactly_once": bands_once,
+                        "bands_per_rank": per_rank_bands})
         rec = {
-            "metric": "G pixel-iterations/s on 4096^2 tile, max_iter=1000 fp64",
+            "metric": metric,
             "value": iters_all * args.steps / elapsed_max / 1e9,
             "unit": "G pixel-iterations/s",
             "n_gpus": world,
@@ -305,40 +406,40 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if args.shard == "tiles" else "strong",
+            "scaling": "strong" if bands_mode else "weak",
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic (coordinates generated in-kernel from the view origin and stride; no RNG)",
-            "config": {"workload": f"{args.workload}: {desc}; one tile per GPU per step, int32 counts "
-                                   "written to resident HBM", "kernel": args.kernel,
-                       "pixels_per_step_per_gpu": npix, "pixel_iterations_per_step_per_gpu": iters_per_step,
-                       "never_escaped_pixels": never, "parallelism": f"{world} independent tile queue(s), no collective",
-                       "streams_per_gpu": max(1, args.streams), "shard": args.shard, "control_backend": backend, "clock_ramp_ms": 0.0 if fake else args.ramp_ms,
-                       "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus,
-                       "clock_mhz": mhz},
+            "config": cfg,
             "roofline": {
                 "bound": "fp64_valu" if args.precision == "f64" else "fp32_valu",
                 "achieved": achieved_tflops,
                 "peak": peak_tflops,
                 "unit": "TFLOP/s",
                 "frac": achieved_tflops / peak_tflops,
-                "traffic": pmc_traffic(args.workload, args.kernel) if args.precision == "f64" else None,
+                "traffic": traffic,
+                "traffic_source": traffic_source,
+                "basis": "whole-job wall time per image per GPU (idle time included)" if bands_mode
+                         else "HIP events around each launch on its stream",
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_ms_min": min(kernel_ms),
                 "flops_per_pixel_iteration": FLOPS_PER_PIXEL_ITER,
                 "valu_slots_per_pixel_iteration": slots,
                 "parity_ceiling_frac": FLOPS_PER_PIXEL_ITER / (2.0 * slots),
-                "valu_slot_util": slots * iters_per_step / avg_kernel_s / peak_lane_ops,
+                "valu_slot_util": slots * per_gpu_iters / avg_kernel_s / peak_lane_ops,
                 "algorithmic_hbm_bytes_per_launch": out_bytes,
                 "hbm_GBps": out_bytes / avg_kernel_s / 1e9,
             },
         }
         if world == 1 and not args.no_cpu_baseline and not fake:
-            rec["cpu_baseline"] = cpu_baseline(workload, args.precision)
+            rec["cpu_baseline"] = cpu_baseline(args.workload, workload, args.precision)
         elif world == 1 and fake:
             rec["cpu_baseline"] = None
         print(json.dumps(rec), flush=True)
 
+    if cursor is not None:
+        barrier()
+        cursor.close()
     if world > 1:
         dist.destroy_process_group()
     if dev is not None:

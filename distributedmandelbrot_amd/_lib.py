@@ -22,8 +22,13 @@ MBK_KERNEL_SIMPLE = 0x100
 MBK_KERNEL_ASM = 0x200
 MBK_KERNEL_REFILL = 0x300
 MBK_KERNEL_GROUP = 0x400
+MBK_KERNEL_SCAN = 0x500
 KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MBK_KERNEL_ASM,
-           "refill": MBK_KERNEL_REFILL, "group": MBK_KERNEL_GROUP}
+           "refill": MBK_KERNEL_REFILL, "group": MBK_KERNEL_GROUP, "scan": MBK_KERNEL_SCAN}
+# enum mbk_option (include/mbk.h), in order
+OPTIONS = {name: i for i, name in enumerate(
+    ["order", "waves_per_wg", "group_steps", "exact_steps", "probe_steps", "scan_steps", "scan_waves",
+     "rf_livemin", "rf_patience", "rf_batch", "rf_waves"])}
 MBK_PRECISION_F32 = 0x1000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
 MBK_SLOTS = 2
@@ -31,7 +36,7 @@ MBK_CODEC_RAW = 0x00
 MBK_CODEC_RLE = 0x01
 MBK_CHUNK_DEFINITION = 4096
 MBK_CHUNK_BYTES = 4096 * 4096
-MBK_ABI_VERSION = 1
+MBK_ABI_VERSION = 2
 
 
 class mbk_view(C.Structure):
@@ -83,6 +88,9 @@ SIGNATURES = {
     "mbk_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(mbk_stats)]),
     "mbk_serialize_last": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                      C.POINTER(C.c_uint32)]),
+    "mbk_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    "mbk_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
+    "mbk_quantise_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mbk_reduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                     C.POINTER(mbk_stats)]),
 }

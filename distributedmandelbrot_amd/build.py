@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmbk_hip.so")
 SOURCES = [os.path.join(CSRC, "mbk_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "mbk_kernels.h"), os.path.join(CSRC, "mbk_refill.h"), os.path.join(CSRC, "mbk_loops.inc"), os.path.join(CSRC, "mbk_persist.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "mbk_kernels.h"), os.path.join(CSRC, "mbk_refill.h"), os.path.join(CSRC, "mbk_loops.inc"), os.path.join(CSRC, "mbk_persist.h"), os.path.join(CSRC, "mbk_scan.h"),
                   os.path.join(os.path.dirname(HERE), "include", "mbk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
@@ -41,13 +41,14 @@ def build(force: bool = False, save_temps: bool = False, verbose: bool = False) 
     if not force and not needs_build():
         return SO
     cmd = [hipcc()] + FLAGS + SOURCES + ["-o", SO]
-    if save_temps:
-        tmp = os.path.join(HERE, "build")
-        os.makedirs(tmp, exist_ok=True)
-        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    cwd = HERE
+    if save_temps:   # intermediate .s / .bc files go to the git-ignored build/ directory
+        cwd = os.path.join(HERE, "build")
+        os.makedirs(cwd, exist_ok=True)
+        cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=HERE)
+    subprocess.check_call(cmd, cwd=cwd)
     return SO
 
 

@@ -15,17 +15,34 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "mbk_kernels.h"
 #include "mbk_refill.h"
 #include "mbk_persist.h"
+#include "mbk_scan.h"
 
 using mbk::Axis;
 using mbk::ReduceOut;
 using mbk::TileArgs;
 using mbk::WorkQueues;
 
-static const int kQueueRing = 8;  // launches in flight on one ctx may overlap by this many
+// Scratch that helper kernels of a launch use (dispatch-order list, work-queue cursors, the scan
+// kernel's deferred-block lists).  It is keyed by the HIP stream the launch goes to: launches on one
+// stream are ordered, so one set per stream can never be rewritten while a kernel still reads it,
+// however many streams the caller uses (round 1 shared a ring of 8 across all streams).
+struct StreamScratch {
+    hipStream_t stream = nullptr;
+    uint32_t *d_order = nullptr;  // heavy-first dispatch order (+2 cursors) of kernels "asm"/"group"
+    size_t order_cap = 0;         // regions
+    WorkQueues *d_queues = nullptr;  // kernel "refill"
+    mbk::ScanCursors *d_cursors = nullptr;  // kernel "scan": two sets, used alternately
+    mbk::ScanEntry *d_entries = nullptr;
+    void *d_state = nullptr;
+    size_t scan_cap_blocks = 0;   // capacity of d_entries / d_state in blocks (state: 64 * 16 B each)
+    unsigned scan_turn = 0;
+};
+static const size_t kMaxStreamScratch = 64;
 
 // One in-flight tile of the host-buffer API: its own stream (so that the D2H of one slot overlaps the
 // kernel of the other), events, device result buffers and reduction scratch.
@@ -44,16 +61,14 @@ struct Slot {
 struct mbk_ctx {
     int device = -1;
     Slot s[MBK_SLOTS];
-    WorkQueues *d_queues = nullptr;  // kQueueRing work-queue blocks for the persistent kernel
-    uint32_t *d_order = nullptr;     // kQueueRing dispatch-order lists (+2 cursors each)
-    size_t order_cap = 0;            // regions per list
+    std::vector<StreamScratch> scratch;  // one per stream seen by this ctx
     size_t last_px = 0;              // pixels of the last tile computed with bytes (for mbk_serialize_last)
     double *d_smooth = nullptr;      // smooth-colouring output of the synchronous API
     size_t smooth_cap_px = 0;
     uint8_t *d_rle = nullptr;        // RLE scratch: block counts | run starts | run values | output stream
     size_t rle_cap_px = 0;
-    unsigned queue_turn = 0;
-    unsigned rf_livemin = 48, rf_patience = 256, rf_waves_per_simd = 8, rf_batch = 1, order = 2, waves_per_wg = 1, lds_pad = 0, probe_steps = 32, group_steps = 8, exact_steps = 8;  // tunables (MBK_* env)
+    uint32_t opt[MBK_OPT_COUNT_];    // tuning options (mbk_set_option); every value is bit-exact
+    int scan_occ[2][2] = {{0, 0}, {0, 0}};  // resident single-wave workgroups per CU: [f64|f32][scan|heavy]
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -169,53 +184,90 @@ static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling, b
     return MBK_OK;
 }
 
+static void free_scratch(StreamScratch &sc)
+{
+    if (sc.d_order) (void)hipFree(sc.d_order);
+    if (sc.d_queues) (void)hipFree(sc.d_queues);
+    if (sc.d_cursors) (void)hipFree(sc.d_cursors);
+    if (sc.d_entries) (void)hipFree(sc.d_entries);
+    if (sc.d_state) (void)hipFree(sc.d_state);
+    sc = StreamScratch();
+}
+
+// The scratch set of `stream` (created on first use).  A caller that keeps creating streams would grow
+// the table without bound, so past kMaxStreamScratch entries everything is drained and dropped.
+static int get_scratch(mbk_ctx *ctx, hipStream_t stream, StreamScratch **out)
+{
+    for (StreamScratch &sc : ctx->scratch)
+        if (sc.stream == stream) {
+            *out = &sc;
+            return MBK_OK;
+        }
+    if (ctx->scratch.size() >= kMaxStreamScratch) {
+        MBK_HIP(ctx, hipDeviceSynchronize());
+        for (StreamScratch &sc : ctx->scratch) free_scratch(sc);
+        ctx->scratch.clear();
+    }
+    ctx->scratch.emplace_back();
+    ctx->scratch.back().stream = stream;
+    *out = &ctx->scratch.back();
+    return MBK_OK;
+}
+
 // Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
 // (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
 static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, bool f32, hipStream_t stream)
 {
-    const uint32_t wpw = ctx->waves_per_wg;  // 8x8-pixel blocks (= waves) per workgroup
+    const uint32_t wpw = ctx->opt[MBK_OPT_WAVES_PER_WG];  // 8x8-pixel blocks (= waves) per workgroup
     a.blocks_x = (a.ncols + 8u * wpw - 1u) / (8u * wpw);
     const uint32_t by = (a.nrows + 7u) / 8u;
     const dim3 grid(a.blocks_x * by), block(64u * wpw);
-    a.perm_mul = ctx->order == 1 ? coprime_multiplier(grid.x) : 1u;
+    const uint32_t order_mode = ctx->opt[MBK_OPT_ORDER], probe_steps = ctx->opt[MBK_OPT_PROBE_STEPS];
+    a.perm_mul = order_mode == 1 ? coprime_multiplier(grid.x) : 1u;
     a.order = nullptr;
-    if (ctx->order == 2 && grid.x >= 4096u && (uint32_t)a.mrd > 2u * ctx->probe_steps) {
+    if (order_mode == 2 && grid.x >= 4096u && (uint32_t)a.mrd > 2u * probe_steps) {
         // heavy-first dispatch order (see classify_blocks_kernel); tiny launches skip it
-        if (grid.x > ctx->order_cap) {
-            if (ctx->d_order) (void)hipFree(ctx->d_order);
-            ctx->d_order = nullptr;
-            ctx->order_cap = 0;
-            MBK_HIP(ctx, hipMalloc((void **)&ctx->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t) * kQueueRing));
-            ctx->order_cap = grid.x;
+        StreamScratch *sc = nullptr;
+        int rc = get_scratch(ctx, stream, &sc);
+        if (rc != MBK_OK) return rc;
+        if (grid.x > sc->order_cap) {
+            // the old list may still be read by a kernel in flight on this stream
+            if (sc->d_order) {
+                MBK_HIP(ctx, hipStreamSynchronize(stream));
+                (void)hipFree(sc->d_order);
+            }
+            sc->d_order = nullptr;
+            sc->order_cap = 0;
+            MBK_HIP(ctx, hipMalloc((void **)&sc->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t)));
+            sc->order_cap = grid.x;
         }
-        uint32_t *ord = ctx->d_order + (ctx->order_cap + 2u) * (ctx->queue_turn++ % kQueueRing);
-        uint32_t *cursors = ord + ctx->order_cap;
+        uint32_t *ord = sc->d_order;
+        uint32_t *cursors = ord + sc->order_cap;
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 2 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, stream, a,
-                           grid.x, 8u * wpw, (int32_t)ctx->probe_steps, ord, cursors);
+                           grid.x, 8u * wpw, (int32_t)probe_steps, ord, cursors);
         a.order = ord;
     }
-    // dynamic LDS is never touched: it only caps how many workgroups a CU admits
     if (f32 && safe)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, ctx->lds_pad, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, 0, stream, a);
     else if (f32 && kernel == MBK_KERNEL_ASM)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, ctx->lds_pad, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, 0, stream, a);
     else if (f32)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, ctx->lds_pad, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, 0, stream, a);
     else if (safe)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, ctx->lds_pad, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, 0, stream, a);
     else if (kernel == MBK_KERNEL_ASM)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, ctx->lds_pad, stream, a);
-    else if (ctx->group_steps == 8)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, ctx->lds_pad, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, 0, stream, a);
+    else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 8)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, 0, stream, a);
     else
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, ctx->lds_pad, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, 0, stream, a);
     MBK_HIP(ctx, hipGetLastError());
     return MBK_OK;
 }
 
 // Can any pixel of the window lie within the ring | |c|^2 - 4 | < 1e-6 ?  (conservative rectangle test)
-static bool window_may_touch_ring(const TileArgs &a)
+static bool window_may_touch_ring(const TileArgs &a, double margin = 1e-6)
 {
     const double x0 = axis_value_host(a.re, a.col0), x1 = axis_value_host(a.re, a.col0 + a.ncols - 1u);
     const double y0 = axis_value_host(a.im, a.row0), y1 = axis_value_host(a.im, a.row0 + a.nrows - 1u);
@@ -224,7 +276,7 @@ static bool window_may_touch_ring(const TileArgs &a)
     const double dy = (ylo <= 0.0 && 0.0 <= yhi) ? 0.0 : std::fmin(std::fabs(ylo), std::fabs(yhi));
     const double fx = std::fmax(std::fabs(xlo), std::fabs(xhi)), fy = std::fmax(std::fabs(ylo), std::fabs(yhi));
     const double rmin2 = dx * dx + dy * dy, rmax2 = fx * fx + fy * fy;
-    return !(rmax2 < 4.0 - 1e-6 || rmin2 > 4.0 + 1e-6);
+    return !(rmax2 < 4.0 - margin || rmin2 > 4.0 + margin);
 }
 
 // Kernel "refill": persistent lane-refill kernel on the interior blocks + "group" on the edge strips.
@@ -250,13 +302,17 @@ static int launch_refill(mbk_ctx *ctx, const TileArgs &a, bool safe, hipStream_t
     q.bxn = icols / 8u;
     q.nblocks = q.bxn * (irows / 8u);
     q.total = (uint32_t)a.mrd - 1u;
-    q.livemin = ctx->rf_livemin;
-    q.patience = ctx->rf_patience;
-    q.batch = ctx->rf_batch;
+    q.livemin = ctx->opt[MBK_OPT_RF_LIVEMIN];
+    q.patience = ctx->opt[MBK_OPT_RF_PATIENCE];
+    q.batch = ctx->opt[MBK_OPT_RF_BATCH];
     q.counts = a.counts;
-    WorkQueues *wq = ctx->d_queues + (ctx->queue_turn++ % kQueueRing);
+    StreamScratch *sc = nullptr;
+    int rcs = get_scratch(ctx, stream, &sc);
+    if (rcs != MBK_OK) return rcs;
+    if (!sc->d_queues) MBK_HIP(ctx, hipMalloc((void **)&sc->d_queues, sizeof(WorkQueues)));
+    WorkQueues *wq = sc->d_queues;
     hipLaunchKernelGGL(mbk::init_queues_kernel, dim3(1), dim3(64), 0, stream, wq, q.nblocks);
-    uint32_t waves = (uint32_t)ctx->prop.multiProcessorCount * 4u * ctx->rf_waves_per_simd;
+    uint32_t waves = (uint32_t)ctx->prop.multiProcessorCount * 4u * ctx->opt[MBK_OPT_RF_WAVES];
     if (waves > q.nblocks) waves = q.nblocks;
     hipLaunchKernelGGL(mbk::tile_persist_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, stream, q, wq);
     MBK_HIP(ctx, hipGetLastError());
@@ -283,9 +339,66 @@ static int launch_refill(mbk_ctx *ctx, const TileArgs &a, bool safe, hipStream_t
     if (a.bytes) {
         const uint64_t npx = (uint64_t)a.ncols * a.nrows;
         hipLaunchKernelGGL(mbk::quantise_kernel, dim3(2048), dim3(256), 0, stream, a.counts, a.bytes, npx, a.mrd,
-                           a.quant_wide);
+                           a.quant_wide, a.quant_rcp);
         MBK_HIP(ctx, hipGetLastError());
     }
+    return MBK_OK;
+}
+
+// Kernel "scan" (default): pass 1 over every 8x8 block with a chip-filling persistent grid, pass 2 over
+// the deferred blocks (mbk_scan.h).  Views that need the literal-doubling loop go to launch_blocks.
+template <typename T>
+static int launch_scan_t(mbk_ctx *ctx, TileArgs a, hipStream_t stream)
+{
+    a.blocks_x = (a.ncols + 7u) / 8u;
+    const uint32_t by = (a.nrows + 7u) / 8u;
+    const uint64_t nblocks64 = (uint64_t)a.blocks_x * by;
+    const uint32_t nblocks = (uint32_t)nblocks64;  // <= 2^31 pixels / 1 -> fits (validate_view)
+    StreamScratch *sc = nullptr;
+    int rc = get_scratch(ctx, stream, &sc);
+    if (rc != MBK_OK) return rc;
+    const uint32_t qcap = (nblocks + mbk::kScanQueues - 1u) / mbk::kScanQueues;
+    const size_t need_blocks = (size_t)qcap * mbk::kScanQueues;
+    if (!sc->d_cursors) {
+        MBK_HIP(ctx, hipMalloc((void **)&sc->d_cursors, 2 * sizeof(mbk::ScanCursors)));
+        MBK_HIP(ctx, hipMemset(sc->d_cursors, 0, 2 * sizeof(mbk::ScanCursors)));  // synchronous, once
+        sc->scan_turn = 0;
+    }
+    if (need_blocks > sc->scan_cap_blocks) {
+        if (sc->d_entries || sc->d_state) MBK_HIP(ctx, hipStreamSynchronize(stream));  // may still be in use
+        if (sc->d_entries) (void)hipFree(sc->d_entries);
+        if (sc->d_state) (void)hipFree(sc->d_state);
+        sc->d_entries = nullptr;
+        sc->d_state = nullptr;
+        sc->scan_cap_blocks = 0;
+        MBK_HIP(ctx, hipMalloc((void **)&sc->d_entries, need_blocks * sizeof(mbk::ScanEntry)));
+        // state is sized for the wider type so that fp32 and fp64 launches can share it
+        MBK_HIP(ctx, hipMalloc(&sc->d_state, need_blocks * 64u * sizeof(mbk::ScanState<double>)));
+        sc->scan_cap_blocks = need_blocks;
+    }
+    mbk::ScanArgs s;
+    s.cur = sc->d_cursors + (sc->scan_turn & 1u);
+    s.cur_next = sc->d_cursors + ((sc->scan_turn + 1u) & 1u);
+    ++sc->scan_turn;
+    s.entries = sc->d_entries;
+    s.state = sc->d_state;
+    s.qcap = qcap;
+    s.nblocks = nblocks;
+    s.scan_steps = a.exact_steps + ctx->opt[MBK_OPT_SCAN_STEPS];
+    // Persistent grids: exactly as many single-wave workgroups as are resident at once (a second round of
+    // a statically strided pass would double its time), capped by the scan_waves option.
+    const int f = sizeof(T) == 4 ? 1 : 0;
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount, cap = 4u * ctx->opt[MBK_OPT_SCAN_WAVES];
+    uint32_t w1 = cus * std::min<uint32_t>((uint32_t)ctx->scan_occ[f][0], cap);
+    uint32_t w2 = cus * std::min<uint32_t>((uint32_t)ctx->scan_occ[f][1], cap);
+    if (w1 > nblocks) w1 = nblocks;
+    if (w2 > nblocks) w2 = nblocks;
+    a.ring_possible = window_may_touch_ring(a, sizeof(T) == 4 ? 2e-3 : 1e-6) ? 1u : 0u;
+    hipLaunchKernelGGL(mbk::tile_scan_kernel<T>, dim3(w1), dim3(64), 0, stream, a, s);
+    // pass 2 has work only if the loop can run past pass 1's depth
+    if ((uint64_t)a.mrd > (uint64_t)s.scan_steps + 1u)
+        hipLaunchKernelGGL(mbk::tile_heavy_kernel<T>, dim3(w2), dim3(64), 0, stream, a, s);
+    MBK_HIP(ctx, hipGetLastError());
     return MBK_OK;
 }
 
@@ -316,8 +429,9 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     a.out_row0 = 0;
     a.mrd = (int32_t)mrd;
     a.quant_wide = (mrd >= (1u << 23)) ? 1u : 0u;
+    a.quant_rcp = mrd ? 1.0 / (double)mrd : 0.0;
     a.perm_mul = 1u;
-    a.exact_steps = ctx->exact_steps;
+    a.exact_steps = ctx->opt[MBK_OPT_EXACT_STEPS];
     a.order = nullptr;
     a.counts = wc ? d_counts : nullptr;
     a.bytes = wb ? d_bytes : nullptr;
@@ -325,11 +439,16 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
 
     const uint32_t kernel = flags & MBK_KERNEL_MASK;
     if (d_smooth && (f32 || kernel == MBK_KERNEL_SIMPLE || kernel == MBK_KERNEL_REFILL))
-        return fail(ctx, MBK_ERR_INVALID, "smooth colouring is implemented by the fp64 asm / group kernels only");
+        return fail(ctx, MBK_ERR_INVALID, "smooth colouring is implemented by the fp64 scan / asm / group kernels only");
     if (f32 && (kernel == MBK_KERNEL_SIMPLE || kernel == MBK_KERNEL_REFILL))
-        return fail(ctx, MBK_ERR_INVALID, "MBK_PRECISION_F32 is implemented by the asm / group kernels only");
+        return fail(ctx, MBK_ERR_INVALID, "MBK_PRECISION_F32 is implemented by the scan / asm / group kernels only");
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
+        case MBK_KERNEL_SCAN:
+            // rare views (tiny imaginary parts / numpy's step == 0 fallback) keep the one-workgroup-per-block path
+            if (safe || a.re.step_is_zero || a.im.step_is_zero)
+                return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+            return f32 ? launch_scan_t<float>(ctx, a, stream) : launch_scan_t<double>(ctx, a, stream);
         case MBK_KERNEL_GROUP:
         case MBK_KERNEL_ASM:
             return launch_blocks(ctx, a, kernel, safe, f32, stream);
@@ -419,16 +538,11 @@ int mbk_create(int device, mbk_ctx **out)
     mbk_ctx *ctx = new (std::nothrow) mbk_ctx();
     if (!ctx) return fail(nullptr, MBK_ERR_NOMEM, "out of host memory");
     ctx->device = device;
-    if (const char *e = std::getenv("MBK_RF_LIVEMIN")) ctx->rf_livemin = (unsigned)std::atoi(e);
-    if (const char *e = std::getenv("MBK_RF_PATIENCE")) ctx->rf_patience = (unsigned)std::atoi(e);
-    if (const char *e = std::getenv("MBK_WPW")) { unsigned w = (unsigned)std::atoi(e); if (w == 1 || w == 2 || w == 4) ctx->waves_per_wg = w; }
-    if (const char *e = std::getenv("MBK_EXACT")) ctx->exact_steps = (unsigned)std::atoi(e);
-    if (const char *e = std::getenv("MBK_GROUP")) ctx->group_steps = (unsigned)std::atoi(e) == 4 ? 4u : 8u;
-    if (const char *e = std::getenv("MBK_PROBE")) ctx->probe_steps = (unsigned)std::atoi(e) > 1 ? (unsigned)std::atoi(e) : 2u;
-    if (const char *e = std::getenv("MBK_LDS")) ctx->lds_pad = (unsigned)std::atoi(e);
-    if (const char *e = std::getenv("MBK_ORDER")) ctx->order = (unsigned)std::atoi(e);
-    if (const char *e = std::getenv("MBK_RF_BATCH")) ctx->rf_batch = (unsigned)std::atoi(e) > 0 ? (unsigned)std::atoi(e) : 1u;
-    if (const char *e = std::getenv("MBK_RF_WAVES")) ctx->rf_waves_per_simd = (unsigned)std::atoi(e);
+    static const uint32_t kDefaults[MBK_OPT_COUNT_] = {
+        /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 8u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
+        /* SCAN_STEPS */ 16u, /* SCAN_WAVES */ 8u,
+        /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u};
+    std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
         hipError_t e2_ = (call);                                                    \
@@ -455,7 +569,16 @@ int mbk_create(int device, mbk_ctx **out)
         MBK_CREATE_HIP(hipMalloc((void **)&sl.d_red, sizeof(ReduceOut)));
         MBK_CREATE_HIP(hipHostMalloc((void **)&sl.h_red, sizeof(ReduceOut), hipHostMallocDefault));
     }
-    MBK_CREATE_HIP(hipMalloc((void **)&ctx->d_queues, sizeof(WorkQueues) * kQueueRing));
+    {
+        const void *fns[2][2] = {{(const void *)mbk::tile_scan_kernel<double>, (const void *)mbk::tile_heavy_kernel<double>},
+                                 {(const void *)mbk::tile_scan_kernel<float>, (const void *)mbk::tile_heavy_kernel<float>}};
+        for (int f = 0; f < 2; ++f)
+            for (int k = 0; k < 2; ++k) {
+                int n = 0;
+                MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fns[f][k], 64, 0));
+                ctx->scan_occ[f][k] = n > 0 ? n : 1;
+            }
+    }
 #undef MBK_CREATE_HIP
     *out = ctx;
     return MBK_OK;
@@ -477,8 +600,8 @@ void mbk_destroy(mbk_ctx *ctx)
         if (sl.ev_c1) (void)hipEventDestroy(sl.ev_c1);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
-    if (ctx->d_queues) (void)hipFree(ctx->d_queues);
-    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (!ctx->scratch.empty()) (void)hipDeviceSynchronize();  // caller streams may still use the scratch
+    for (StreamScratch &sc : ctx->scratch) free_scratch(sc);
     if (ctx->d_rle) (void)hipFree(ctx->d_rle);
     if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
     delete ctx;
@@ -709,7 +832,6 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
                  total_bytes = off_out + 1 + n;
     if (n > ctx->rle_cap_px) {
         if (ctx->d_rle) (void)hipFree(ctx->d_rle);
-    if (ctx->d_smooth) (void)hipFree(ctx->d_smooth);
         ctx->d_rle = nullptr;
         ctx->rle_cap_px = 0;
         MBK_HIP(ctx, hipMalloc((void **)&ctx->d_rle, total_bytes));
@@ -744,6 +866,58 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
         MBK_HIP(ctx, hipMemcpyAsync(h_out + 1, ctx->s[0].d_bytes, n, hipMemcpyDeviceToHost, s));
     }
     MBK_HIP(ctx, hipStreamSynchronize(s));
+    return MBK_OK;
+}
+
+int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
+{
+    if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
+    bool ok = false;
+    switch (option) {
+        case MBK_OPT_ORDER: ok = value <= 2u; break;
+        case MBK_OPT_WAVES_PER_WG: ok = value == 1u || value == 2u || value == 4u; break;
+        case MBK_OPT_GROUP_STEPS: ok = value == 4u || value == 8u; break;
+        case MBK_OPT_EXACT_STEPS: ok = value <= 4096u; break;
+        case MBK_OPT_PROBE_STEPS: ok = value >= 2u && value <= 65536u; break;
+        case MBK_OPT_SCAN_STEPS: ok = value % 16u == 0u && value <= 65536u; break;
+        case MBK_OPT_SCAN_WAVES: ok = value >= 1u && value <= 8u; break;
+        case MBK_OPT_RF_LIVEMIN: ok = value <= 63u; break;
+        case MBK_OPT_RF_PATIENCE: ok = value >= 16u && value <= (1u << 20); break;
+        case MBK_OPT_RF_BATCH: ok = value >= 1u && value <= 64u; break;
+        case MBK_OPT_RF_WAVES: ok = value >= 1u && value <= 8u; break;
+        default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
+    }
+    if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");
+    ctx->opt[option] = value;
+    return MBK_OK;
+}
+
+int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value)
+{
+    if (!ctx || !value) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    if (option < 0 || option >= MBK_OPT_COUNT_) return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
+    *value = ctx->opt[option];
+    return MBK_OK;
+}
+
+int mbk_quantise_counts(mbk_ctx *ctx, const int32_t *h_counts, uint64_t n, uint32_t mrd, uint8_t *h_bytes)
+{
+    if (!ctx || !h_counts || !h_bytes) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    if (mrd == 0 || mrd > 0x7fffffffu) return fail(ctx, MBK_ERR_INVALID, "mrd must be in [1, 2^31)");
+    if (n == 0) return MBK_OK;
+    if (n > (1ull << 31)) return fail(ctx, MBK_ERR_INVALID, "more than 2^31 counts");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    Slot &sl = ctx->s[0];
+    if (sl.busy) return fail(ctx, MBK_ERR_INVALID, "slot 0 has a tile in flight: call mbk_wait first");
+    int rc = ensure_buffers(ctx, sl, (size_t)n);
+    if (rc != MBK_OK) return rc;
+    MBK_HIP(ctx, hipMemcpyAsync(sl.d_counts, h_counts, n * sizeof(int32_t), hipMemcpyHostToDevice, sl.stream));
+    hipLaunchKernelGGL(mbk::quantise_kernel, dim3(2048), dim3(256), 0, sl.stream, sl.d_counts, sl.d_bytes, n,
+                       (int32_t)mrd, mrd >= (1u << 23) ? 1u : 0u, 1.0 / (double)mrd);
+    MBK_HIP(ctx, hipGetLastError());
+    MBK_HIP(ctx, hipMemcpyAsync(h_bytes, sl.d_bytes, n, hipMemcpyDeviceToHost, sl.stream));
+    MBK_HIP(ctx, hipStreamSynchronize(sl.stream));
+    ctx->last_px = 0;
     return MBK_OK;
 }
 

@@ -43,7 +43,9 @@ struct TileArgs {
     uint32_t out_pitch, out_col0, out_row0;  // output element = (row + out_row0) * out_pitch + col + out_col0
     int32_t mrd;
     uint32_t quant_wide;  // 1: count*256+mrd-1 does not fit 32 bits -> 64-bit quantiser division
+    double quant_rcp;     // fl(1/mrd), host-computed: the narrow quantiser divides by multiplying (see quantise)
     uint32_t exact_steps; // steps tested one by one before the grouped test takes over
+    uint32_t ring_possible;  // scan: 0 = the host proved that no pixel of the window lies near |c| = 2
     uint32_t perm_mul;    // workgroup order: block = (blockIdx * perm_mul) mod gridDim (1 = row-major)
     const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel)
     int32_t *counts;      // may be null
@@ -66,15 +68,26 @@ __device__ __forceinline__ double axis_value(const Axis &a, uint32_t k)
 }
 
 // W.py:96-98 in exact integer form: ceil(count*256/mrd) mod 256 (proved equal to the float form:
-// tests/test_oracle.py::test_quantiser_integer_form).
-__device__ __forceinline__ uint8_t quantise(int32_t count, int32_t mrd, uint32_t wide)
+// tests/test_oracle.py::test_quantiser_integer_form), i.e. floor(x / mrd) mod 256 with
+// x = count*256 + mrd - 1.  The 32-bit integer division costs ~25 VALU instructions per pixel -- a third
+// of everything a fast-escaping block executes -- so the narrow path (mrd < 2^23) divides by multiplying:
+//     q = trunc(fma((double)x, rcp, 2^-30)),  rcp = fl(1/mrd).
+// Exact: count <= mrd-1 gives x/mrd < 2^9, so the fma's total error is below 2^-43; a non-integer
+// quotient has a fractional part in [2^-23, 1 - 2^-23], which neither the error nor the 2^-30 bias can
+// carry across an integer; an integer quotient k lands in [k + 2^-30 - 2^-43, k + 2^-30 + 2^-43].
+// (tests/test_oracle.py::test_quantiser_reciprocal_form restates this with exact rationals.)
+__device__ __forceinline__ uint8_t quantise(int32_t count, int32_t mrd, uint32_t wide, double rcp)
 {
     if (wide) {
         uint64_t x = (uint64_t)(uint32_t)count * 256ull + (uint64_t)(uint32_t)mrd - 1ull;
         return (uint8_t)(x / (uint64_t)(uint32_t)mrd);
     }
-    uint32_t x = (uint32_t)count * 256u + (uint32_t)mrd - 1u;
-    return (uint8_t)(x / (uint32_t)mrd);
+    const uint32_t x = (uint32_t)count * 256u + (uint32_t)mrd - 1u;
+    return (uint8_t)(uint32_t)__builtin_fma((double)x, rcp, 0x1p-30);
+}
+__device__ __forceinline__ uint8_t quantise(int32_t count, const TileArgs &p)
+{
+    return quantise(count, p.mrd, p.quant_wide, p.quant_rcp);
 }
 
 // BASELINE config 5 (NOT in the reference): continuous ("smooth") escape-time value at the
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
     const int32_t count = escape_count<kFmaDouble>(cr, ci, p.mrd);
     const size_t o = (size_t)lr * p.ncols + lc;
     if (p.counts) p.counts[o] = count;
-    if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
+    if (p.bytes) p.bytes[o] = quantise(count, p);
 }
 
 // The hand-scheduled loops (kernels "asm" and "group") live in mbk_loops.inc, instantiated for
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     }
     const size_t o = (size_t)(lr + p.out_row0) * p.out_pitch + lc + p.out_col0;
     if (p.counts) p.counts[o] = count;
-    if (p.bytes) p.bytes[o] = quantise(count, p.mrd, p.quant_wide);
+    if (p.bytes) p.bytes[o] = quantise(count, p);
     if (p.smooth) p.smooth[o] = smooth_value(count, (double)m);
 }
 

@@ -136,11 +136,11 @@ __global__ __launch_bounds__(256) void tile_persist_kernel(PersistArgs p, WorkQu
 // counts -> quantised bytes for launches whose kernel wrote counts only
 __global__ __launch_bounds__(256) void quantise_kernel(const int32_t *__restrict__ counts,
                                                        uint8_t *__restrict__ bytes, uint64_t n, int32_t mrd,
-                                                       uint32_t wide)
+                                                       uint32_t wide, double rcp)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        bytes[i] = quantise(counts[i], mrd, wide);
+        bytes[i] = quantise(counts[i], mrd, wide, rcp);
 }
 
 }  // namespace mbk

@@ -125,6 +125,23 @@ class MandelbrotDevice:
         buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning option (include/mbk.h enum mbk_option; names in _lib.OPTIONS).  Scheduling only:
+        every accepted value gives bit-identical results."""
+        self._check(self._lib.mbk_set_option(self._h, L.OPTIONS[name], int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_uint32(0)
+        self._check(self._lib.mbk_get_option(self._h, L.OPTIONS[name], C.byref(v)))
+        return int(v.value)
+
+    def quantise_counts(self, counts: np.ndarray, mrd: int) -> np.ndarray:
+        """The device's quantiser alone (WorkerCUDA.py:96-98) on host int32 counts in [0, mrd-1]."""
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        out = np.empty(counts.shape, np.uint8)
+        self._check(self._lib.mbk_quantise_counts(self._h, counts.ctypes.data, counts.size, mrd, out.ctypes.data))
+        return out
+
     # -- compute ---------------------------------------------------------------------------
     @staticmethod
     def _cview(view: View, window) -> L.mbk_view:

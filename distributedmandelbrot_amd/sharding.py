@@ -11,6 +11,10 @@ whichever worker asks next (Distributer.cs:335-353).
 """
 from __future__ import annotations
 
+import fcntl
+import mmap
+import os
+import struct
 import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -57,6 +61,51 @@ class WorkQueue:
 
     def __len__(self) -> int:
         return len(self._items)
+
+
+class SharedCursor:
+    """One work cursor shared by the processes of a node (one process per GPU under torch.distributed.run):
+    an int64 in a /dev/shm file, advanced under an fcntl lock.  This is the cross-process form of
+    WorkQueue -- dynamic assignment with no collective and no RCCL: band cost varies >100x, so a static
+    split leaves GPUs idle.  `next()` returns 0, 1, 2, ... each exactly once over all
+    processes; the caller maps tickets to work items (bench.py: ticket -> (step, band))."""
+
+    def __init__(self, name: str, create: bool):
+        root = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+        self.path = os.path.join(root, f"mbk_cursor_{name}")
+        self._owner = create
+        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
+        self._fd = os.open(self.path, flags, 0o600)
+        if create:
+            os.write(self._fd, struct.pack("<q", 0))
+        self._map = mmap.mmap(self._fd, 8)
+
+    def next(self, count: int = 1) -> int:
+        fcntl.lockf(self._fd, fcntl.LOCK_EX)
+        try:
+            (v,) = struct.unpack_from("<q", self._map, 0)
+            struct.pack_into("<q", self._map, 0, v + count)
+            return v
+        finally:
+            fcntl.lockf(self._fd, fcntl.LOCK_UN)
+
+    def reset(self, value: int = 0) -> None:
+        fcntl.lockf(self._fd, fcntl.LOCK_EX)
+        try:
+            struct.pack_into("<q", self._map, 0, value)
+        finally:
+            fcntl.lockf(self._fd, fcntl.LOCK_UN)
+
+    def close(self) -> None:
+        if self._map is not None:
+            self._map.close()
+            os.close(self._fd)
+            self._map = None
+            if self._owner:
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
 
 
 def render_view(devices: Sequence, view, mrd: int, *, band_rows: int = 128, want_counts: bool = True,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MBK_ABI_VERSION 1
+#define MBK_ABI_VERSION 2
 
 /* DataChunk.cs:20 (dataChunkRange), WorkerCUDA.py:80 (definition = 4096). */
 #define MBK_CHUNK_DEFINITION 4096u
@@ -44,15 +44,17 @@ enum mbk_status {
 /* flags for the compute calls */
 #define MBK_WANT_COUNTS 0x1u /* write int32 escape indices (what calc_mb_value returns, WorkerCUDA.py:39) */
 #define MBK_WANT_BYTES 0x2u  /* write the quantised uint8 (WorkerCUDA.py:96-98) -- fused on device */
-/* Kernel selection (bits 8..11).  0 = default (fastest parity-exact kernel). Others exist so that the
- * parity tests and bench.py can A/B every shipped kernel variant; all of them are bit-exact. */
+/* Kernel selection (bits 8..11).  0 = default (fastest parity-exact kernel: "scan"). Others exist so that
+ * the parity tests and bench.py can A/B every shipped kernel variant; all of them are bit-exact. */
 #define MBK_KERNEL_SHIFT 8
 #define MBK_KERNEL_MASK 0xF00u
 #define MBK_KERNEL_DEFAULT 0x000u
 #define MBK_KERNEL_SIMPLE 0x100u /* one lane per pixel, compiler-scheduled loop, literal (2*zr)*zi form */
 #define MBK_KERNEL_ASM 0x200u    /* one lane per pixel, hand-scheduled gfx950 loop */
 #define MBK_KERNEL_REFILL 0x300u /* persistent waves with lane refill (deep-zoom divergence) */
-#define MBK_KERNEL_GROUP 0x400u  /* hand-scheduled loop, bailout tested once per 4 steps + exact replay */
+#define MBK_KERNEL_GROUP 0x400u  /* hand-scheduled loop, bailout tested once per 8 steps + exact replay; one workgroup per 8x8 block */
+#define MBK_KERNEL_SCAN 0x500u   /* the same loops in two persistent passes: a chip-filling scan that finishes every block
+                                    whose pixels escape early, then a work-queue pass over the deferred blocks */
 
 /* Arithmetic of the escape loop (bit 12).  Default = IEEE binary64, the reference's arithmetic.
  * MBK_PRECISION_F32 is BASELINE config 4's "fp32 kernel variant" -- NOT in the reference (its only
@@ -134,9 +136,9 @@ int mbk_datachunk_geometry(uint32_t level, uint32_t index_real, uint32_t index_i
  * with MBK_WANT_BYTES, the host quantiser (:96-98).  d_counts: int32[nrows*ncols] (or NULL without
  * MBK_WANT_COUNTS); d_bytes: uint8[nrows*ncols] (or NULL without MBK_WANT_BYTES).
  * mrd is the reference's "maximum recursion depth": at most mrd-1 updates, result in {0} U [1, mrd-1].
- * A launch may enqueue small helper kernels (dispatch-order pre-pass, work-queue reset) that use
- * per-ctx scratch from a ring of 8 slots: keep at most 8 launches of one ctx in flight ACROSS
- * different streams (launches on one stream are ordered and may be queued without limit).
+ * A launch may enqueue helper kernels (scan pass, dispatch-order pre-pass, work-queue reset) that use
+ * scratch memory the ctx keeps PER STREAM (up to 18 B per pixel of the largest window seen on that
+ * stream): launches on one stream are ordered, so any number may be queued, on any number of streams.
  */
 int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
                     int32_t *d_counts, uint8_t *d_bytes, void *hip_stream);
@@ -193,6 +195,34 @@ int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats);
  * cross PCIe.  h_out must hold *size <= 1 + n bytes; cap is its capacity (MBK_ERR_INVALID if too
  * small, with *size set to the needed size). */
 int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *size, uint32_t *codec);
+
+/*
+ * Tuning options.  They change scheduling only -- every value the setter accepts gives bit-identical
+ * results (tests/test_gpu_parity.py::test_option_matrix_is_bit_exact) -- and the library reads NO
+ * environment variable.  mbk_set_option returns MBK_ERR_INVALID for an unknown option or a value out of
+ * range.  Defaults in brackets.
+ */
+enum mbk_option {
+    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] heavy-first list */
+    MBK_OPT_WAVES_PER_WG,  /* asm/group: 8x8 blocks per workgroup: [1], 2, 4 */
+    MBK_OPT_GROUP_STEPS,   /* group: steps per grouped bailout test: 4, [8] */
+    MBK_OPT_EXACT_STEPS,   /* scan/group: steps tested one by one before the grouped test takes over: 0..4096 [8] */
+    MBK_OPT_PROBE_STEPS,   /* asm/group: depth of the heavy-first probe: 2..65536 [32] */
+    MBK_OPT_SCAN_STEPS,    /* scan: grouped steps pass 1 runs after the exact ones, a multiple of 16: 0..65536 [16] */
+    MBK_OPT_SCAN_WAVES,    /* scan: resident waves per SIMD of both passes: 1..[8] */
+    MBK_OPT_RF_LIVEMIN,    /* refill: refill when this many lanes or fewer are live: 0..63 [48] */
+    MBK_OPT_RF_PATIENCE,   /* refill: steps between forced refill checks: 16..2^20 [256] */
+    MBK_OPT_RF_BATCH,      /* refill: blocks per queue pop: 1..64 [1] */
+    MBK_OPT_RF_WAVES,      /* refill: resident waves per SIMD: 1..[8] */
+    MBK_OPT_COUNT_
+};
+int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value);
+int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value);
+
+/* The quantiser alone, on the device: h_bytes[i] = uint8(ceil(h_counts[i] * 256 / mrd)) for n host counts
+ * (WorkerCUDA.py:96-98; each count must lie in [0, mrd-1], which is what calc_mb_value returns).
+ * Exists so that the exactness of the device's division-free form can be checked for every count. */
+int mbk_quantise_counts(mbk_ctx *ctx, const int32_t *h_counts, uint64_t n, uint32_t mrd, uint8_t *h_bytes);
 
 /* Device-side reduction over int32 counts already in HBM (asynchronous part on hip_stream -- NULL =
  * the null stream -- then a stream sync): fills stats->pixel_iterations and stats->never_pixels.  Used by bench.py to turn

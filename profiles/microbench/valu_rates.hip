@@ -13,7 +13,9 @@
 
 
 
-enum Kind { FMA_IND, MUL_IND, ADD_IND, FMA_DEP, MUL_DEP, ADD_DEP, CMP_F64, CMP_U32, ADD_U32, MOV_B32, FMA_F32, BODY, BODY2, BODY_CMP };
+enum Kind { FMA_IND, MUL_IND, ADD_IND, FMA_DEP, MUL_DEP, ADD_DEP, CMP_F64, CMP_U32, ADD_U32, MOV_B32, FMA_F32, BODY, BODY2, BODY_CMP,
+            PK_FMA_F32, PK_MUL_F32, PK_ADD_F32, MUL_F32, ADD_F32, FMA_CONST, SQR_F64, BODY_PK };
+typedef float float2_ __attribute__((ext_vector_type(2)));
 
 template <int KIND>
 __global__ __launch_bounds__(256) void rate_kernel(unsigned long long *cycles, unsigned long long *wall, double *sink, double seed, int ITERS)
@@ -25,6 +27,12 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long *cycles, u
     // mandelbrot state (c inside the set so nothing overflows): two independent pixels
     double cr = -0.1 + 1e-6 * threadIdx.x, ci = 0.2, zr = cr, zi = ci, aa = zr * zr, bb = zi * zi, t, p, m;
     double cr2 = -0.2 + 1e-6 * threadIdx.x, ci2 = 0.1, zr2 = cr2, zi2 = ci2, aa2 = zr2 * zr2, bb2 = zi2 * zi2, t2, p2, m2;
+    // packed fp32: two values per lane in a 64-bit register pair (v_pk_*_f32)
+    float2_ q0 = {f0, f1}, q1 = {f1, f2}, q2 = {f2, f3}, q3 = {f3, f0}, q4 = {f0 + 4, f1}, q5 = {f1 + 4, f2}, q6 = {f2 + 4, f3},
+            q7 = {f3 + 4, f0}, qa = {fa, fa}, qb = {fb, fb};
+    // packed mandelbrot state: two pixels per lane
+    float2_ pcr = {-0.1f + 1e-4f * threadIdx.x, -0.2f + 1e-4f * threadIdx.x}, pci = {0.2f, 0.1f}, pzr = pcr, pzi = pci,
+            paa = pzr * pzr, pbb = pzi * pzi, pt, pp, ptwo = {2.0f, 2.0f};
     unsigned long long w0 = wall_clock64();
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int i = 0; i < ITERS; ++i) {
@@ -72,6 +80,45 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long *cycles, u
 #define R(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(fa), "v"(fb));
             R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3)
 #undef R
+        } else if (KIND == PK_FMA_F32) {
+#define R(x) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(qa), "v"(qb));
+            R(q0) R(q1) R(q2) R(q3) R(q4) R(q5) R(q6) R(q7) R(q0) R(q1) R(q2) R(q3) R(q4) R(q5) R(q6) R(q7)
+#undef R
+        } else if (KIND == PK_MUL_F32) {
+#define R(x) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(x) : "v"(qa));
+            R(q0) R(q1) R(q2) R(q3) R(q4) R(q5) R(q6) R(q7) R(q0) R(q1) R(q2) R(q3) R(q4) R(q5) R(q6) R(q7)
+#undef R
+        } else if (KIND == PK_ADD_F32) {
+#define R(x) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(qb));
+            R(q0) R(q1) R(q2) R(q3) R(q4) R(q5) R(q6) R(q7) R(q0) R(q1) R(q2) R(q3) R(q4) R(q5) R(q6) R(q7)
+#undef R
+        } else if (KIND == MUL_F32) {
+#define R(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(fa));
+            R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3)
+#undef R
+        } else if (KIND == ADD_F32) {
+#define R(x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(fb));
+            R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3) R(f0) R(f1) R(f2) R(f3)
+#undef R
+        } else if (KIND == FMA_CONST) {
+#define R(x) asm volatile("v_fma_f64 %0, %0, 2.0, %1" : "+v"(x) : "v"(b));
+            R(x0) R(x1) R(x2) R(x3) R(x4) R(x5) R(x6) R(x7) R(x0) R(x1) R(x2) R(x3) R(x4) R(x5) R(x6) R(x7)
+#undef R
+        } else if (KIND == SQR_F64) {
+#define R(x) asm volatile("v_mul_f64 %0, %0, %0" : "+v"(x));
+            R(x0) R(x1) R(x2) R(x3) R(x4) R(x5) R(x6) R(x7) R(x0) R(x1) R(x2) R(x3) R(x4) R(x5) R(x6) R(x7)
+#undef R
+        } else if (KIND == BODY_PK) {
+            // two packed-fp32 steps: 6 packed ops per step = 2 pixels per lane
+#define IT                                                                                       \
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(pt) : "v"(paa), "v"(pbb));   \
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(pp) : "v"(pzr), "v"(pzi));                \
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(pzr) : "v"(pt), "v"(pcr));                \
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pzi) : "v"(pp), "v"(ptwo), "v"(pci)); \
+            asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(paa) : "v"(pzr));                         \
+            asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(pbb) : "v"(pzi));
+            IT IT
+#undef IT
         } else if (KIND == BODY || KIND == BODY_CMP) {
             // two iterations of one pixel per loop trip (7 fp64 ops each)
 #define IT                                                                                       \
@@ -110,12 +157,15 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned long long *cycles, u
     double r = 0;
     if (KIND <= ADD_DEP || KIND == CMP_F64) r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
     else if (KIND == CMP_U32 || KIND == ADD_U32 || KIND == MOV_B32) r = u0 + u1 + u2;
-    else if (KIND == FMA_F32) r = f0 + f1 + f2 + f3;
+    else if (KIND == FMA_F32 || KIND == MUL_F32 || KIND == ADD_F32) r = f0 + f1 + f2 + f3;
+    else if (KIND == PK_FMA_F32 || KIND == PK_MUL_F32 || KIND == PK_ADD_F32) { float2_ qs = q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7; r = qs.x + qs.y; }
+    else if (KIND == BODY_PK) r = pzr.x + pzr.y + pzi.x + pzi.y + paa.x + pbb.y;
+    else if (KIND == FMA_CONST || KIND == SQR_F64) r = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
     else r = zr + zi + zr2 + zi2 + m + m2;
     sink[gid] = r;
 }
 
-static int instr_per_iter(int kind) { return kind == BODY ? 14 : kind == BODY_CMP ? 16 : kind == BODY2 ? 14 : 16; }
+static int instr_per_iter(int kind) { return kind == BODY ? 14 : kind == BODY_CMP ? 16 : kind == BODY2 ? 14 : kind == BODY_PK ? 12 : 16; }
 
 template <int KIND>
 void run(const char *name, int cus)
@@ -157,11 +207,22 @@ void run(const char *name, int cus)
     }
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool only_new = argc > 1;   // any argument: only the kinds added in round 2
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     printf("device %s arch %s CUs %d clock %d MHz\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
     const int cus = prop.multiProcessorCount;
+    run<PK_FMA_F32>("pk_fma_f32", cus);
+    run<PK_MUL_F32>("pk_mul_f32", cus);
+    run<PK_ADD_F32>("pk_add_f32", cus);
+    run<FMA_F32>("fma_f32", cus);
+    run<MUL_F32>("mul_f32", cus);
+    run<ADD_F32>("add_f32", cus);
+    run<BODY_PK>("body_pk", cus);
+    run<FMA_CONST>("fma_f64c", cus);
+    run<SQR_F64>("sqr_f64", cus);
+    if (only_new) return 0;
     run<FMA_IND>("fma_f64", cus);
     run<MUL_IND>("mul_f64", cus);
     run<ADD_IND>("add_f64", cus);

@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from distributedmandelbrot_amd import MandelbrotDevice, View
 from oracle.oracle import COracle
 
-kernel = sys.argv[1] if len(sys.argv) > 1 else "refill"
+kernel = sys.argv[1] if len(sys.argv) > 1 else "scan"
 o = COracle()
 dev = MandelbrotDevice(0)
 cases = [(View(-2.0, -1.5, 3.0, 3.0, 16, 16), 50), (View(-2.0, -1.5, 3.0, 3.0, 64, 48), 100),

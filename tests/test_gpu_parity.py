@@ -12,7 +12,7 @@ from distributedmandelbrot_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = ["default", "simple", "asm", "refill", "group"]
+KERNELS = ["default", "simple", "asm", "refill", "group", "scan"]
 
 
 def _check_view(gpu, oracle, view, mrd, window=None, kernel="default"):
@@ -203,7 +203,7 @@ def test_render_view_multi_queue_single_gpu(gpu, oracle):
     assert per[0]["bands"] == 8 and per[0]["pixel_iterations"] == total
 
 
-@pytest.mark.parametrize("kernel", ["default", "asm", "group"])
+@pytest.mark.parametrize("kernel", ["default", "asm", "group", "scan"])
 def test_f32_variant_against_f32_oracle(gpu, oracle, kernel):
     """BASELINE cfg4 (fp32 kernel variant): bit-exact against the strict-binary32 oracle."""
     rs = np.random.RandomState(4)
@@ -231,7 +231,7 @@ def test_f32_variant_against_f32_oracle(gpu, oracle, kernel):
         gpu.compute_view(View(1e30, 0.0, 1.0, 1.0, 4, 4), 10, precision="f32")   # beyond the fp32 domain
 
 
-@pytest.mark.parametrize("kernel", ["default", "asm", "group"])
+@pytest.mark.parametrize("kernel", ["default", "asm", "group", "scan"])
 def test_smooth_colouring_cfg5(gpu, oracle, kernel):
     """BASELINE cfg5: integer part (the count) bit-exact, the continuous value within 1e-12 of the libm
     evaluation of the same formula on the same |z_n|^2."""
@@ -299,3 +299,163 @@ def test_two_tiles_in_flight_submit_wait(gpu, golden):
         assert st.never_pixels == int(golden[f"full/{keys[i - 1]}/zeros"])
     with pytest.raises(MbkError):
         gpu.wait(0)                                               # nothing in flight
+
+
+# ------------------------------------------------------------------------------------------------------
+# Round 2: BASELINE configs at their NAMED sizes, the option matrix, and regression tests for round-1 bugs
+# ------------------------------------------------------------------------------------------------------
+
+CFG3 = (View(-0.743648, 0.131820, 1e-5, 1e-5, 8192, 8192), 10000)      # BASELINE configs[2]
+CFG4 = (View(-0.755, 0.10, 0.02, 0.02, 16384, 16384), 50000)           # BASELINE configs[3] (fp32)
+CFG5 = (View(-2.0, -1.5, 3.0, 3.0, 4096, 4096), 5000)                  # BASELINE configs[4] (smooth)
+
+
+@pytest.fixture(scope="module")
+def cfg3_oracle_counts(oracle):
+    """cfg3 at full size from the 8-lane AVX-512 evaluation of the oracle (bit-identical to the scalar
+    one: tests/test_oracle.py); ~65 G pixel-iterations, a few seconds on the GPU box's host cores."""
+    view, mrd = CFG3
+    if not oracle.have_avx512():
+        pytest.skip("host without AVX-512: the scalar oracle needs minutes for cfg3")
+    counts, total = oracle.view_avx512(view.start_r, view.start_i, view.range_r, view.range_i, view.width,
+                                       view.height, mrd)
+    return counts, total
+
+
+@pytest.mark.parametrize("kernel", ["default", "refill", "group"])
+def test_full_size_cfg3_deep_zoom(gpu, cfg3_oracle_counts, kernel):
+    """BASELINE cfg3 (8192^2 deep zoom, mrd 10000) at its named size: counts bit-exact, bytes equal to the
+    quantised oracle counts; `refill` (persistent lane-refill kernel + edge strips) included."""
+    view, mrd = CFG3
+    oc, total = cfg3_oracle_counts
+    c, b, st = gpu.compute_view(view, mrd, kernel=kernel)
+    assert np.array_equal(c, oc), (kernel, int((c != oc).sum()))
+    assert st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum())
+    ob = ((oc.astype(np.int64) * 256 + mrd - 1) // mrd).astype(np.uint8)     # SURVEY.md A.4 integer form
+    assert np.array_equal(b, ob), kernel
+    # row bands (the multi-GPU shard unit) at full width equal the whole
+    for row0, nrows in [(0, 128), (4096 - 64, 128), (8192 - 72, 72)]:
+        cb, _, _ = gpu.compute_view(view, mrd, window=(0, row0, 8192, nrows), want_bytes=False, kernel=kernel)
+        assert np.array_equal(cb, oc[row0:row0 + nrows]), (kernel, row0)
+
+
+@pytest.mark.parametrize("kernel", ["default", "group"])
+def test_cfg4_full_width_bands_f32(gpu, oracle, kernel):
+    """BASELINE cfg4 (16384^2 seahorse valley, mrd 50000, fp32 variant): 8 full-width 8-row bands spread
+    over the image, bit-exact against the strict-binary32 oracle."""
+    view, mrd = CFG4
+    for row0 in [0, 2048 + 8, 4096, 6000, 8192 - 8, 10240, 13000, 16384 - 8]:
+        window = (0, row0, 16384, 8)
+        c, b, st = gpu.compute_view(view, mrd, window=window, kernel=kernel, precision="f32")
+        oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width,
+                                    view.height, mrd, window=window, precision="f32")
+        assert np.array_equal(c, oc), (kernel, row0, int((c != oc).sum()))
+        assert np.array_equal(b, ob) and st.pixel_iterations == total, (kernel, row0)
+
+
+def test_full_size_cfg5_smooth(gpu, oracle):
+    """BASELINE cfg5 (4096^2, mrd 5000, continuous colouring) at its named size: counts bit-exact, the
+    continuous value within 1e-12 * mrd of the libm evaluation on the same |z_n|^2."""
+    view, mrd = CFG5
+    sm, c, st = gpu.compute_view_smooth(view, mrd)
+    osm, oc = oracle.view_smooth(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd)
+    assert np.array_equal(c, oc), int((c != oc).sum())
+    esc = oc > 0
+    assert (sm[~esc] == 0.0).all()
+    assert float(np.abs(sm[esc] - osm[esc]).max()) <= 1e-12 * mrd
+    assert st.pixel_iterations == int(np.where(oc > 0, oc, mrd - 1).astype(np.int64).sum())
+
+
+def test_smooth_buffer_survives_serialize_last(gpu, oracle):
+    """Round-1 bug: mbk_serialize_last freed the smooth buffer while growing its RLE scratch; the next
+    compute_view_smooth wrote into freed HBM.  Sequence smooth -> datachunk -> serialize_last -> smooth on a
+    FRESH ctx (so that the RLE scratch really grows after the smooth buffer exists)."""
+    from distributedmandelbrot_amd import MandelbrotDevice
+    from oracle.serializer import serialize
+    view, mrd = View(-0.755, 0.10, 0.02, 0.02, 700, 500), 900
+    osm, oc = oracle.view_smooth(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd)
+    with MandelbrotDevice(0) as dev:
+        sm1, c1, _ = dev.compute_view_smooth(view, mrd)
+        byts, _, _ = dev.datachunk(10, 1024, 3, 5)
+        stream, codec = dev.serialize_last()
+        assert stream == serialize(byts)
+        sm2, c2, _ = dev.compute_view_smooth(view, mrd)
+        byts2, _, _ = dev.datachunk(10, 1024, 3, 5)          # device buffers still intact afterwards
+        sm3, c3, _ = dev.compute_view_smooth(view, mrd)
+    for sm, c in ((sm1, c1), (sm2, c2), (sm3, c3)):
+        assert np.array_equal(c, oc)
+        assert np.allclose(sm[oc > 0], osm[oc > 0], rtol=0, atol=1e-12 * mrd) and (sm[oc == 0] == 0).all()
+    assert np.array_equal(byts, byts2)
+
+
+OPTION_MATRIX = [
+    ("scan", {"exact_steps": 0}), ("scan", {"exact_steps": 3}), ("scan", {"scan_steps": 0}),
+    ("scan", {"scan_steps": 48}), ("scan", {"scan_waves": 1}), ("scan", {"scan_waves": 3, "exact_steps": 16}),
+    ("group", {"exact_steps": 0}), ("group", {"exact_steps": 5}), ("group", {"group_steps": 4}),
+    ("group", {"waves_per_wg": 2}), ("group", {"waves_per_wg": 4, "order": 1}), ("group", {"order": 0}),
+    ("group", {"order": 1}), ("group", {"probe_steps": 2}), ("asm", {"waves_per_wg": 4, "order": 0}),
+    ("refill", {"rf_livemin": 0}), ("refill", {"rf_livemin": 63, "rf_patience": 16}),
+    ("refill", {"rf_batch": 4, "rf_waves": 2}),
+]
+
+
+@pytest.mark.parametrize("kernel,options", OPTION_MATRIX, ids=lambda x: str(x))
+def test_option_matrix_is_bit_exact(oracle, kernel, options):
+    """Every tuning option the library accepts (mbk_set_option; no environment variable is read) changes
+    scheduling only.  A fresh ctx per case; seeded small views + cfg2 at full size against the oracle."""
+    from distributedmandelbrot_amd import MandelbrotDevice, MbkError
+    rs = np.random.RandomState(5)
+    cases = [(View(-2.0, -1.5, 3.0, 3.0, 4096, 4096), 1000), (View(-2.0, -2.0, 4.0, 4.0, 300, 200), 40),
+             (View(-0.743648, 0.131820, 1e-5, 1e-5, 200, 136), 4000), (View(-0.2, -0.1, 0.2, 0.2, 64, 64), 100)]
+    for _ in range(10):
+        cr, ci = rs.uniform(-1.6, 0.4), rs.uniform(-1.1, 1.1)
+        span = 10.0 ** rs.uniform(-6, 0)
+        cases.append((View(cr, ci, span, span * rs.uniform(0.5, 2.0), int(rs.randint(1, 300)), int(rs.randint(1, 300))),
+                      int(rs.choice([2, 9, 10, 17, 18, 24, 25, 26, 33, 41, 100, 700]))))
+    with MandelbrotDevice(0) as dev:
+        for name, value in options.items():
+            dev.set_option(name, value)
+            assert dev.get_option(name) == value
+        with pytest.raises(MbkError):
+            dev.set_option("group_steps", 5)
+        with pytest.raises(MbkError):
+            dev.set_option("scan_steps", 17)
+        for view, mrd in cases:
+            _check_view(dev, oracle, view, mrd, kernel=kernel)
+
+
+def test_quantiser_every_count_on_device(gpu, oracle):
+    """The device divides by multiplying with a host reciprocal (mbk_kernels.h: quantise); check it
+    against the reference's float form (WorkerCUDA.py:96-98, restated by the oracle) for EVERY count of
+    many mrd, including the 64-bit path (mrd >= 2^23)."""
+    from oracle.oracle import numpy_quantise
+    for mrd in [1, 2, 3, 7, 255, 256, 257, 1000, 1024, 4999, 5000, 10000, 50000, 65535, 65536, 999983,
+                2 ** 23 - 1, 2 ** 23, 2 ** 23 + 1, 2 ** 24 + 3, 2 ** 31 - 1]:
+        if mrd <= 2 ** 22:
+            counts = np.arange(mrd, dtype=np.int32)
+        else:   # every count near both ends and around each byte boundary, plus a dense random sample
+            k = np.arange(1, 257, dtype=np.int64) * mrd // 256
+            edge = np.concatenate([k + d for d in range(-3, 4)])
+            rs = np.random.RandomState(mrd % 1000)
+            counts = np.unique(np.clip(np.concatenate([np.arange(4096), mrd - 1 - np.arange(4096), edge,
+                                                       rs.randint(0, mrd, 1 << 20)]), 0, mrd - 1)).astype(np.int32)
+        got = gpu.quantise_counts(counts, mrd)
+        assert np.array_equal(got, numpy_quantise(counts, mrd)), mrd
+
+
+def test_launches_on_many_streams_have_private_scratch(gpu, oracle):
+    """Helper-kernel scratch is kept per stream (round 1 shared a ring of 8 across streams): 12 launches in
+    flight on 12 torch streams, scan / group / refill mixed, every result bit-exact."""
+    import torch
+    view, mrd = View(-0.755, 0.10, 0.02, 0.02, 1024, 768), 1500
+    oc, _, _ = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, 1024, 768, mrd, want_bytes=False)
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    outs = [torch.full((768 * 1024,), -7, dtype=torch.int32, device="cuda:0") for _ in streams]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, (s, o) in enumerate(zip(streams, outs)):
+            gpu.launch_view(view, mrd, d_counts=o.data_ptr(), stream=s.cuda_stream,
+                            kernel=["scan", "group", "refill"][(i + rep) % 3])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy().reshape(768, 1024), oc)

@@ -170,3 +170,28 @@ def test_avx512_baseline_is_bit_identical_to_scalar_oracle(oracle):
         c, _, total = oracle.view(sr, si, rr, ri, w, h, mrd, want_bytes=False)
         c2, total2 = oracle.view_avx512(sr, si, rr, ri, w, h, mrd)
         assert np.array_equal(c, c2) and total == total2
+
+
+def test_quantiser_reciprocal_form():
+    """The device's division-free quantiser (csrc/mbk_kernels.h: q = trunc(fma(x, fl(1/mrd), 2^-30)) with
+    x = count*256 + mrd - 1) restated with exact rationals: float(Fraction) is the correctly rounded fma.
+    Every count for small mrd; byte boundaries, both ends and a random sample for large mrd < 2^23."""
+    from fractions import Fraction
+    bias = Fraction(1, 2 ** 30)
+
+    def device_form(count: int, mrd: int) -> int:
+        rcp = Fraction(1.0 / mrd)                       # the host's correctly rounded reciprocal, exactly
+        x = count * 256 + mrd - 1
+        return int(float(x * rcp + bias)) & 0xFF        # one rounding, like v_fma_f64; trunc; uint8 wrap
+
+    rs = np.random.RandomState(11)
+    for mrd in [1, 2, 3, 7, 100, 255, 256, 257, 1000, 1023, 1024, 5000]:
+        for count in range(mrd):
+            assert device_form(count, mrd) == ((count * 256 + mrd - 1) // mrd) & 0xFF, (count, mrd)
+    for mrd in [10000, 50000, 65535, 999983, 2 ** 22 + 1, 2 ** 23 - 1]:
+        ks = np.arange(1, 257, dtype=np.int64) * mrd // 256
+        counts = set(int(c) for d in range(-2, 3) for c in ks + d) | set(range(64)) | set(range(mrd - 64, mrd)) \
+            | set(int(c) for c in rs.randint(0, mrd, 3000))
+        for count in counts:
+            if 0 <= count < mrd:
+                assert device_form(count, mrd) == ((count * 256 + mrd - 1) // mrd) & 0xFF, (count, mrd)

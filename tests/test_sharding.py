@@ -100,6 +100,62 @@ def test_bench_distributed_path_gloo_world2():
     assert abs(rec["value"] - 2 * 1.0 * 3 / (rec["ms_per_step"] * 3 / 1e3)) / rec["value"] < 1e-6
 
 
+def test_bench_bands_dynamic_cursor_gloo_world2():
+    """--shard bands: one image per step cut into row bands that the ranks pull from the shared-memory
+    cursor (no RCCL, no static split).  Two CPU processes over gloo with the stub backend: every
+    (step, band) ticket of the timed region is computed exactly once, and both ranks got work."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MBK_BENCH_FAKE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg3", "--shard", "bands"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    cfg = rec["config"]
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and cfg["control_backend"] == "gloo"
+    assert cfg["bands_per_image"] == 32 and cfg["band_rows"] == 256          # >= 16 bands per GPU
+    assert cfg["bands_exactly_once"] is True
+    assert sum(cfg["bands_per_rank"]) == 3 * 32 and min(cfg["bands_per_rank"]) > 0
+    assert not os.path.exists(os.path.join("/dev/shm", "mbk_cursor_%d_none" % port))
+
+
+def _cursor_worker(name, n, q):
+    from distributedmandelbrot_amd.sharding import SharedCursor
+    c = SharedCursor(name, create=False)
+    got = []
+    while True:
+        t = c.next()
+        if t >= n:
+            break
+        got.append(t)
+    c.close()
+    q.put(got)
+
+
+def test_shared_cursor_across_processes():
+    import multiprocessing as mp
+    from distributedmandelbrot_amd.sharding import SharedCursor
+    name = f"test_{os.getpid()}"
+    owner = SharedCursor(name, create=True)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cursor_worker, args=(name, 5000, q)) for _ in range(4)]
+        [p.start() for p in procs]
+        got = [q.get(timeout=120) for _ in procs]
+        [p.join(timeout=60) for p in procs]
+        assert sorted(x for g in got for x in g) == list(range(5000))
+        owner.reset(7)
+        assert owner.next(3) == 7 and owner.next() == 10
+    finally:
+        owner.close()
+    assert not os.path.exists(owner.path)
+
+
 def test_bench_json_contract_single_rank_fake():
     """The one-line JSON of bench.py carries every field the round contract names (checked on the CPU
     with the stub backend; the real numbers come from the GPU run)."""
@@ -116,6 +172,6 @@ def test_bench_json_contract_single_rank_fake():
     assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["vs_baseline"] is None
     assert rec["unit"] == "G pixel-iterations/s" and rec["dtype"] == "f64" and "workload" in rec["config"]
     assert "model" not in rec["config"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert key in rec["roofline"], key
     assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-12
