@@ -92,6 +92,9 @@ def parse_args():
                     help="f32 = BASELINE cfg4's fp32 kernel variant (not in the reference); default f64, cfg4: f32")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning option (include/mbk.h enum mbk_option), e.g. --opt scan_steps=32; repeatable")
+    ap.add_argument("--outputs", default="counts", choices=["counts", "both"],
+                    help="counts (default, the contract's workload): int32 escape indices. both: also the quantised "
+                         "uint8 tile the worker sends (what a DataChunk launch writes), for kernel studies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", default="tiles", choices=["tiles", "bands"],
                     help="tiles (default): every rank computes its own tile per step (weak scaling). bands: ONE "
@@ -260,10 +263,12 @@ def main():
         for k, v in options.items():
             dev.set_option(k, v)
         device_info = dev.info()
+        device_info["scan_occupancy"] = dev.scan_occupancy()
         view = View(sr, si, rng, rng, width, height)
         nbuf = 1 if bands_mode else nstreams
         d_counts_all = [torch.empty(npix, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(nbuf)]
         d_smooth_all = [torch.empty(npix, dtype=torch.float64, device=f"cuda:{local_rank}") for _ in range(nbuf)] if smooth else None
+        d_bytes_all = [torch.empty(npix, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(nbuf)] if args.outputs == "both" else None
         streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
         slot_events = [None] * nstreams
 
@@ -273,6 +278,7 @@ def main():
                                        stream=streams[i].cuda_stream, kernel=args.kernel)
             else:
                 dev.launch_view(view, mrd, d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
+                                d_bytes=d_bytes_all[i].data_ptr() if d_bytes_all else 0,
                                 kernel=args.kernel, precision=args.precision)
 
         def launch_band(i, bnd):   # a row band of the shared view, written at its place in this rank's image
@@ -388,12 +394,13 @@ def main():
         cfg = {"workload": f"{args.workload}: {desc}; " + (
                    f"one image per step cut into {len(bands)} row bands of {band_rows} rows pulled from a shared cursor"
                    if bands_mode else "one tile per GPU per step") + ", int32 counts written to resident HBM",
-               "kernel": args.kernel, "options": options,
+               "kernel": args.kernel, "options": options, "outputs": args.outputs,
                "pixels_per_step": npix * (1 if bands_mode else world), "pixel_iterations_per_step_per_gpu": per_gpu_iters,
                "never_escaped_pixels": never, "parallelism": f"{world} independent work queue(s), no collective",
                "streams_per_gpu": nstreams, "shard": args.shard, "control_backend": backend,
                "clock_ramp_ms": 0.0 if fake or bands_mode else args.ramp_ms,
-               "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz}
+               "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz,
+               "occupancy_api_wg_per_cu": device_info.get("scan_occupancy")}
         if bands_mode:
             cfg.update({"bands_per_image": len(bands), "band_rows": band_rows, "bands_exactly_once": bands_once,
                         "bands_per_rank": per_rank_bands})

@@ -41,6 +41,8 @@ struct StreamScratch {
     void *d_state = nullptr;
     size_t scan_cap_blocks = 0;   // capacity of d_entries / d_state in blocks (state: 64 * 16 B each)
     unsigned scan_turn = 0;
+    uint32_t *h_hint = nullptr;   // pinned, written by the kernels of the last launch on this stream:
+                                  // [0] longest deferred list (scan pass 2), [1] share of heavy blocks x 65536
 };
 static const size_t kMaxStreamScratch = 64;
 
@@ -191,6 +193,7 @@ static void free_scratch(StreamScratch &sc)
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
     if (sc.d_state) (void)hipFree(sc.d_state);
+    if (sc.h_hint) (void)hipHostFree(sc.h_hint);
     sc = StreamScratch();
 }
 
@@ -209,8 +212,11 @@ static int get_scratch(mbk_ctx *ctx, hipStream_t stream, StreamScratch **out)
         ctx->scratch.clear();
     }
     ctx->scratch.emplace_back();
-    ctx->scratch.back().stream = stream;
-    *out = &ctx->scratch.back();
+    StreamScratch &sc = ctx->scratch.back();
+    sc.stream = stream;
+    *out = &sc;
+    MBK_HIP(ctx, hipHostMalloc((void **)&sc.h_hint, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    sc.h_hint[0] = sc.h_hint[1] = 0xffffffffu;   // nothing known yet
     return MBK_OK;
 }
 
@@ -242,11 +248,12 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             sc->order_cap = grid.x;
         }
         uint32_t *ord = sc->d_order;
-        uint32_t *cursors = ord + sc->order_cap;
+        uint32_t *cursors = ord + grid.x;   // right behind the list: the tile kernel finds them at order[gridDim.x]
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 2 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, stream, a,
                            grid.x, 8u * wpw, (int32_t)probe_steps, ord, cursors);
         a.order = ord;
+        a.heavy_hint = sc->h_hint + 1;
     }
     if (f32 && safe)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, 0, stream, a);
@@ -361,7 +368,9 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, hipStream_t stream)
     const size_t need_blocks = (size_t)qcap * mbk::kScanQueues;
     if (!sc->d_cursors) {
         MBK_HIP(ctx, hipMalloc((void **)&sc->d_cursors, 2 * sizeof(mbk::ScanCursors)));
-        MBK_HIP(ctx, hipMemset(sc->d_cursors, 0, 2 * sizeof(mbk::ScanCursors)));  // synchronous, once
+        // once per stream, ON that stream: hipMemset on the null stream does not order against a
+        // non-blocking stream (the first launch on a new stream raced with it and lost deferred blocks)
+        MBK_HIP(ctx, hipMemsetAsync(sc->d_cursors, 0, 2 * sizeof(mbk::ScanCursors), stream));
         sc->scan_turn = 0;
     }
     if (need_blocks > sc->scan_cap_blocks) {
@@ -385,14 +394,39 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, hipStream_t stream)
     s.qcap = qcap;
     s.nblocks = nblocks;
     s.scan_steps = a.exact_steps + ctx->opt[MBK_OPT_SCAN_STEPS];
-    // Persistent grids: exactly as many single-wave workgroups as are resident at once (a second round of
-    // a statically strided pass would double its time), capped by the scan_waves option.
+    // Pass 1 is a persistent grid: exactly as many single-wave workgroups as are resident at once (a second
+    // round of a statically strided pass would double its time) -- what the occupancy query reports for the
+    // kernel (7 waves per SIMD: it keeps ~100 kernel arguments and loop constants in SGPRs; capping them for
+    // an 8th wave costs 15 spills per block), capped by the scan_waves option.
     const int f = sizeof(T) == 4 ? 1 : 0;
-    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount, cap = 4u * ctx->opt[MBK_OPT_SCAN_WAVES];
-    uint32_t w1 = cus * std::min<uint32_t>((uint32_t)ctx->scan_occ[f][0], cap);
-    uint32_t w2 = cus * std::min<uint32_t>((uint32_t)ctx->scan_occ[f][1], cap);
-    if (w1 > nblocks) w1 = nblocks;
-    if (w2 > nblocks) w2 = nblocks;
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    const uint32_t per_cu = std::min<uint32_t>(4u * ctx->opt[MBK_OPT_SCAN_WAVES], (uint32_t)ctx->scan_occ[f][0]);
+    const uint32_t wmax = cus * per_cu;
+    uint32_t w1 = std::min(wmax, nblocks);
+    // pass 1: a whole number of block rows per sweep keeps a wave in one block column for col_period sweeps
+    // (the real coordinate is computed once per column) -- unless that would idle more than a quarter of the chip
+    if (a.blocks_x <= w1 && (w1 / a.blocks_x) * a.blocks_x * 4u >= w1 * 3u) w1 = (w1 / a.blocks_x) * a.blocks_x;
+    s.stride = w1;
+    s.stride_bx = w1 % a.blocks_x;
+    s.stride_by = w1 / a.blocks_x;
+    // XCD-aware column order: pays when the quantised bytes are written (8-byte row segments: the
+    // all-exterior DataChunk takes 63 us without it, 44 us with it), nothing for int32 counts alone
+    const uint32_t xm = ctx->opt[MBK_OPT_SCAN_XCD_MAP];
+    s.xcd_map = ((xm == 1u || (xm == 2u && a.bytes != nullptr)) && s.stride_bx == 0u && a.blocks_x % 32u == 0u) ? 1u : 0u;
+    // column jump: ~5/16 of the width, a multiple of 32 columns when the XCD map is on (keeps its grouping)
+    s.col_period = ctx->opt[MBK_OPT_SCAN_COL_PERIOD];
+    if (s.xcd_map) s.col_jump = 32u * (((a.blocks_x / 32u) * 5u / 16u) | 1u);
+    else s.col_jump = std::max(1u, a.blocks_x * 5u / 16u);
+    if (s.col_jump >= a.blocks_x) s.col_jump = 0u, s.col_period = 0u;
+    // pass 2: 64 lists x (hint = longest list of the previous launch on this stream + 25 %)
+    // Never fewer workgroups than fill the chip (when the tile has that many blocks): a hint from a light
+    // tile followed by a heavy one would otherwise leave a few waves looping over whole lists.
+    const uint32_t hint = sc->h_hint[0];
+    s.ranks2 = hint == 0xffffffffu ? qcap : (uint32_t)std::min<uint64_t>(qcap, (uint64_t)hint + hint / 4u + 2u);
+    s.ranks2 = std::max(s.ranks2, std::min(qcap, (cus * 32u + mbk::kScanQueues - 1u) / mbk::kScanQueues));
+    if (s.ranks2 == 0u) s.ranks2 = 1u;
+    s.hint_out = sc->h_hint;
+    const uint32_t w2 = mbk::kScanQueues * s.ranks2;
     a.ring_possible = window_may_touch_ring(a, sizeof(T) == 4 ? 2e-3 : 1e-6) ? 1u : 0u;
     hipLaunchKernelGGL(mbk::tile_scan_kernel<T>, dim3(w1), dim3(64), 0, stream, a, s);
     // pass 2 has work only if the loop can run past pass 1's depth
@@ -444,11 +478,26 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
         return fail(ctx, MBK_ERR_INVALID, "MBK_PRECISION_F32 is implemented by the scan / asm / group kernels only");
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
-        case MBK_KERNEL_SCAN:
+        case MBK_KERNEL_SCAN: {
             // rare views (tiny imaginary parts / numpy's step == 0 fallback) keep the one-workgroup-per-block path
             if (safe || a.re.step_is_zero || a.im.step_is_zero)
                 return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+            // Default = whichever of the two was the better choice for the PREVIOUS launch on this stream
+            // (both leave the share of heavy blocks in pinned memory; no host round trip, and a stale or
+            // wrong hint only costs time).  With more than ~1 % of the blocks heavy the tile is bound by
+            // their arithmetic and the light blocks ride along for free in "group" (cfg2: scan 617 us,
+            // group 568); below that, "group" is bound by its 0.27 ns per workgroup and "scan" wins
+            // (all-exterior tile: 43 us against 71).  Small launches always take "scan".
+            if (kernel == MBK_KERNEL_DEFAULT && (uint64_t)((a.ncols + 7u) / 8u) * ((a.nrows + 7u) / 8u) >= 16384u) {
+                StreamScratch *sc = nullptr;
+                rc = get_scratch(ctx, stream, &sc);
+                if (rc != MBK_OK) return rc;
+                const uint32_t share = sc->h_hint[1];
+                if (share != 0xffffffffu && share > ctx->opt[MBK_OPT_HEAVY_SHARE])
+                    return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+            }
             return f32 ? launch_scan_t<float>(ctx, a, stream) : launch_scan_t<double>(ctx, a, stream);
+        }
         case MBK_KERNEL_GROUP:
         case MBK_KERNEL_ASM:
             return launch_blocks(ctx, a, kernel, safe, f32, stream);
@@ -540,7 +589,7 @@ int mbk_create(int device, mbk_ctx **out)
     ctx->device = device;
     static const uint32_t kDefaults[MBK_OPT_COUNT_] = {
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 8u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
-        /* SCAN_STEPS */ 16u, /* SCAN_WAVES */ 8u,
+        /* SCAN_STEPS */ 16u, /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 2u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
@@ -750,6 +799,15 @@ int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, u
     return submit_view(ctx, ctx->s[slot], &v, mrd, MBK_WANT_BYTES | (h_counts ? MBK_WANT_COUNTS : 0u), h_counts, h_bytes);
 }
 
+int mbk_view_submit(mbk_ctx *ctx, int slot, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                    int32_t *h_counts, uint8_t *h_bytes)
+{
+    if (!ctx || !view) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    if (slot < 0 || slot >= MBK_SLOTS) return fail(ctx, MBK_ERR_INVALID, "slot out of range");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    return submit_view(ctx, ctx->s[slot], view, mrd, flags, h_counts, h_bytes);
+}
+
 int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats)
 {
     if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
@@ -881,6 +939,9 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_PROBE_STEPS: ok = value >= 2u && value <= 65536u; break;
         case MBK_OPT_SCAN_STEPS: ok = value % 16u == 0u && value <= 65536u; break;
         case MBK_OPT_SCAN_WAVES: ok = value >= 1u && value <= 8u; break;
+        case MBK_OPT_SCAN_XCD_MAP: ok = value <= 2u; break;
+        case MBK_OPT_SCAN_COL_PERIOD: ok = value <= 65536u; break;
+        case MBK_OPT_HEAVY_SHARE: ok = value <= 65536u; break;
         case MBK_OPT_RF_LIVEMIN: ok = value <= 63u; break;
         case MBK_OPT_RF_PATIENCE: ok = value >= 16u && value <= (1u << 20); break;
         case MBK_OPT_RF_BATCH: ok = value >= 1u && value <= 64u; break;
@@ -895,6 +956,11 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
 int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value)
 {
     if (!ctx || !value) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    if (option >= MBK_INFO_SCAN_WG_PER_CU && option < MBK_INFO_SCAN_WG_PER_CU + 4) {
+        const int k = option - MBK_INFO_SCAN_WG_PER_CU;   // [f64 scan, f64 heavy, f32 scan, f32 heavy]
+        *value = (uint32_t)ctx->scan_occ[k >> 1][k & 1];
+        return MBK_OK;
+    }
     if (option < 0 || option >= MBK_OPT_COUNT_) return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     *value = ctx->opt[option];
     return MBK_OK;

@@ -48,6 +48,8 @@ struct TileArgs {
     uint32_t ring_possible;  // scan: 0 = the host proved that no pixel of the window lies near |c| = 2
     uint32_t perm_mul;    // workgroup order: block = (blockIdx * perm_mul) mod gridDim (1 = row-major)
     const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel)
+    uint32_t *heavy_hint;  // optional, pinned host memory: with `order`, workgroup 0 reports the share of
+                           // probe-heavy regions (x 65536) -- next launch's kernel choice (mbk_api.hip)
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
     double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value
@@ -178,6 +180,8 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     // or perm_mul != 1 (multiplicative permutation, coprime to the grid size).
     const uint32_t blk = p.order ? p.order[blockIdx.x]
                                  : (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
+    if (p.order && p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)   // cursors sit behind the list
+        *p.heavy_hint = (uint32_t)(((uint64_t)p.order[gridDim.x] << 16) / gridDim.x);
     const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
     const uint32_t lc = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);  // one 8x8 block per wave
     const uint32_t lr = by * 8u + (lane >> 3);

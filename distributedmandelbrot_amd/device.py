@@ -135,6 +135,15 @@ class MandelbrotDevice:
         self._check(self._lib.mbk_get_option(self._h, L.OPTIONS[name], C.byref(v)))
         return int(v.value)
 
+    def scan_occupancy(self) -> dict:
+        """hipOccupancyMaxActiveBlocksPerMultiprocessor of the scan-path kernels (single-wave workgroups per CU)."""
+        out = {}
+        for k, name in enumerate(["f64_scan", "f64_heavy", "f32_scan", "f32_heavy"]):
+            v = C.c_uint32(0)
+            self._check(self._lib.mbk_get_option(self._h, 100 + k, C.byref(v)))
+            out[name] = int(v.value)
+        return out
+
     def quantise_counts(self, counts: np.ndarray, mrd: int) -> np.ndarray:
         """The device's quantiser alone (WorkerCUDA.py:96-98) on host int32 counts in [0, mrd-1]."""
         counts = np.ascontiguousarray(counts, dtype=np.int32)
@@ -225,6 +234,22 @@ class MandelbrotDevice:
         assert out_bytes.dtype == np.uint8 and out_bytes.size == L.MBK_CHUNK_BYTES and out_bytes.flags.c_contiguous
         self._check(self._lib.mbk_datachunk_submit(self._h, slot, level, mrd, index_real, index_imag,
                                                    out_bytes.ctypes.data, None))
+
+    def submit_view(self, slot: int, view: View, mrd: int, *, window=None, out_counts: Optional[np.ndarray] = None,
+                    out_bytes: Optional[np.ndarray] = None, kernel: str = "default", precision: str = "f64") -> None:
+        """Enqueue a view / window on `slot` and return at once; the given host arrays (C-contiguous, sized
+        for the window; slices of a larger image are fine) are valid after wait(slot)."""
+        cv = self._cview(view, window)
+        n = cv.nrows * cv.ncols
+        flags = L.KERNELS[kernel] | L.PRECISIONS[precision]
+        for arr, dt, flag in ((out_counts, np.int32, L.MBK_WANT_COUNTS), (out_bytes, np.uint8, L.MBK_WANT_BYTES)):
+            if arr is not None:
+                assert arr.dtype == dt and arr.size == n and arr.flags.c_contiguous
+                flags |= flag
+        self._check(self._lib.mbk_view_submit(
+            self._h, slot, C.byref(cv), mrd, flags,
+            out_counts.ctypes.data if out_counts is not None else None,
+            out_bytes.ctypes.data if out_bytes is not None else None))
 
     def wait(self, slot: int) -> TileStats:
         st = L.mbk_stats()

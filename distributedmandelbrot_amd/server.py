@@ -31,14 +31,15 @@ DEFAULT_DISTRIBUTER_PORT = 59010  # Program.cs:13
 DEFAULT_DATA_SERVER_PORT = 59011  # Program.cs:14
 
 
-def _recv_exact(c: socket.socket, n: int) -> bytes:
-    buf = bytearray()
-    while len(buf) < n:
-        part = c.recv(n - len(buf))
-        if not part:
-            raise ConnectionError("peer closed")
-        buf += part
-    return bytes(buf)
+def _recv_exact(c: socket.socket, n: int) -> bytearray:
+    buf = bytearray(n)
+    view, got = memoryview(buf), 0
+    while got < n:
+        k = c.recv_into(view[got:], n - got)
+        if k == 0:
+            raise ConnectionError(f"peer closed after {got} of {n} bytes")
+        got += k
+    return buf
 
 
 class _TcpLoop:
@@ -100,6 +101,7 @@ class Distributer(_TcpLoop):
         self.lease_seconds = lease_seconds
         self._state = threading.Lock()
         self.leases: List[Tuple[Workload, float]] = []
+        self.receiving: dict = {}   # leases claimed by a response whose payload is still arriving
         # completed is keyed without mrd, like the index (Distributer.cs:165-175)
         self.completed = set(store.completed()) if store is not None else set()
         self.rejected: List[Workload] = []
@@ -109,7 +111,7 @@ class Distributer(_TcpLoop):
     def _next_needed(self) -> Optional[Workload]:
         now = time.monotonic()
         self.leases = [(w, t) for w, t in self.leases if now < t]  # the 5-minute sweeper, :153-160
-        leased = {w for w, _ in self.leases}
+        leased = {w for w, _ in self.leases} | set(self.receiving)
         for level, mrd in self.level_settings:
             for ir in range(level):
                 for ii in range(level):
@@ -133,19 +135,31 @@ class Distributer(_TcpLoop):
         elif op == 0x01:
             w = struct.unpack("<IIII", _recv_exact(c, 16))
             now = time.monotonic()
+            # Claim the lease in the same critical section that tests it: the reference handles one
+            # connection at a time (Distributer.cs:226-297), so of two responses for one tile (an expired
+            # worker and its successor) the second is rejected (:404-423).  With a thread per connection
+            # the claim must be explicit, or both would be accepted and stored.
             with self._state:
-                live = any(lw == w and now < t for lw, t in self.leases)
-            if not live:
+                claimed = None
+                for k, (lw, t) in enumerate(self.leases):
+                    if lw == w and now < t:
+                        claimed = self.leases.pop(k)
+                        self.receiving[w] = claimed
+                        break
+            if claimed is None:
                 self.rejected.append(w)
                 c.sendall(bytes([0x21]))
                 return
-            c.sendall(bytes([0x20]))
-            payload = np.frombuffer(_recv_exact(c, CHUNK_BYTES), dtype=np.uint8)
+            try:
+                c.sendall(bytes([0x20]))
+                payload = np.frombuffer(_recv_exact(c, CHUNK_BYTES), dtype=np.uint8)
+            except BaseException:
+                with self._state:       # the tile did not arrive: the lease is live again
+                    self.receiving.pop(w, None)
+                    self.leases.append(claimed)
+                raise
             with self._state:
-                for k, (lw, t) in enumerate(self.leases):
-                    if lw == w:
-                        del self.leases[k]
-                        break
+                self.receiving.pop(w, None)
                 self.completed.add((w[0], w[2], w[3]))
             if self.store is not None:  # the reference saves on a thread-pool task (Distributer.cs:436-442)
                 self.store.save_chunk(w[0], w[2], w[3], payload)
@@ -156,7 +170,7 @@ class Distributer(_TcpLoop):
 
     def all_done(self) -> bool:
         with self._state:
-            return self._next_needed() is None and not self.leases
+            return self._next_needed() is None and not self.leases and not self.receiving
 
 
 class DataServer(_TcpLoop):

@@ -109,35 +109,67 @@ class SharedCursor:
 
 
 def render_view(devices: Sequence, view, mrd: int, *, band_rows: int = 128, want_counts: bool = True,
-                want_bytes: bool = True, kernel: str = "default"
+                want_bytes: bool = True, kernel: str = "default", out_counts: Optional[np.ndarray] = None,
+                out_bytes: Optional[np.ndarray] = None
                 ) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], List[dict]]:
     """Compute a whole view on several GPUs of this process: one host thread per device pulling row
-    bands from a shared WorkQueue.  `devices` are MandelbrotDevice-like objects (anything with
-    compute_view(view, mrd, window=..., want_counts=..., want_bytes=..., kernel=...)).
+    bands from a shared WorkQueue, two bands in flight per device (submit_view / wait), every band
+    DMA'd straight into its rows of the final image -- no per-band temporary, no second copy.
+    `out_counts` / `out_bytes` (height x width) may be supplied by the caller, e.g. pinned arrays from
+    MandelbrotDevice.pinned_empty (4x the D2H rate of pageable memory; they live as long as that device).
+    `devices` are MandelbrotDevice-like objects: submit_view(slot, view, mrd, window=..., out_counts=...,
+    out_bytes=..., kernel=...) + wait(slot), or -- simpler stand-ins -- just compute_view(...).
     Returns (counts | None, bytes | None, per-device stats)."""
     bands = make_bands(view.height, band_rows)
     queue = WorkQueue(bands)
-    counts = np.empty((view.height, view.width), np.int32) if want_counts else None
-    byts = np.empty((view.height, view.width), np.uint8) if want_bytes else None
+    shape = (view.height, view.width)
+    counts = byts = None
+    if want_counts:
+        counts = out_counts if out_counts is not None else np.empty(shape, np.int32)
+        assert counts.shape == shape and counts.dtype == np.int32 and counts.flags.c_contiguous
+    if want_bytes:
+        byts = out_bytes if out_bytes is not None else np.empty(shape, np.uint8)
+        assert byts.shape == shape and byts.dtype == np.uint8 and byts.flags.c_contiguous
     per_dev = [{"bands": 0, "pixel_iterations": 0, "kernel_ms": 0.0} for _ in devices]
     errors: List[BaseException] = []
+
+    def rows(arr, band):
+        return arr[band.row0:band.row0 + band.nrows] if arr is not None else None
+
+    def account(slot: int, st) -> None:
+        per_dev[slot]["bands"] += 1
+        per_dev[slot]["pixel_iterations"] += st.pixel_iterations
+        per_dev[slot]["kernel_ms"] += st.kernel_ms
 
     def feeder(slot: int) -> None:
         dev = devices[slot]
         try:
+            if not hasattr(dev, "submit_view"):      # synchronous stand-in: still no temporary
+                while True:
+                    band = queue.pop()
+                    if band is None:
+                        return
+                    _, _, st = dev.compute_view(view, mrd, window=(0, band.row0, view.width, band.nrows),
+                                                want_counts=want_counts, want_bytes=want_bytes, kernel=kernel,
+                                                out_counts=rows(counts, band), out_bytes=rows(byts, band))
+                    account(slot, st)
+            busy = [False, False]
+            s = 0
             while True:
                 band = queue.pop()
-                if band is None:
+                if band is not None:
+                    if busy[s]:
+                        account(slot, dev.wait(s))
+                    dev.submit_view(s, view, mrd, window=(0, band.row0, view.width, band.nrows),
+                                    out_counts=rows(counts, band), out_bytes=rows(byts, band), kernel=kernel)
+                    busy[s] = True
+                    s ^= 1
+                else:
+                    for k in (s, s ^ 1):
+                        if busy[k]:
+                            account(slot, dev.wait(k))
+                            busy[k] = False
                     return
-                c, b, st = dev.compute_view(view, mrd, window=(0, band.row0, view.width, band.nrows),
-                                            want_counts=want_counts, want_bytes=want_bytes, kernel=kernel)
-                if counts is not None:
-                    counts[band.row0:band.row0 + band.nrows] = c
-                if byts is not None:
-                    byts[band.row0:band.row0 + band.nrows] = b
-                per_dev[slot]["bands"] += 1
-                per_dev[slot]["pixel_iterations"] += st.pixel_iterations
-                per_dev[slot]["kernel_ms"] += st.kernel_ms
         except BaseException as e:
             errors.append(e)
 

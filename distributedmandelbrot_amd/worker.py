@@ -19,6 +19,10 @@ Differences from the reference worker, all wire-compatible:
   * `run_farm`: one feeder thread per GPU, each an ordinary protocol client (the Distributer accepts
     any number of clients, Distributer.cs:226-297) -- the per-GPU work queue IS the Distributer's
     lease table, so there is no RCCL and no GPU<->GPU traffic;
+  * `run_pipelined` (what run_farm runs per GPU): the same two exchanges per tile, but overlapped --
+    while tile n is on the GPU, tile n+1 is being leased and tile n-1 is being sent by a sender thread
+    (two tiles in flight on the device: mbk_datachunk_submit / mbk_wait); the reference is strictly
+    lease -> compute -> send (WorkerCUDA.py:111-176);
   * there is no CPU fallback: without libmbk_hip.so and a gfx950 GPU, process_workload raises.
 """
 from __future__ import annotations
@@ -126,9 +130,21 @@ def request_workload(addr: str, port: int, timeout: Optional[float] = None) -> O
         raise Exception("Unknown response code to request: " + str(response))  # WorkerCUDA.py:131-132
 
 
-def submit_workload(addr: str, port: int, workload: Workload, out: np.ndarray,
-                    timeout: Optional[float] = None) -> bool:
-    """Second connection of WorkerCUDA.py:148-172.  True == accepted and sent, False == 0x21."""
+SUBMIT_REJECTED, SUBMIT_ACCEPTED, SUBMIT_RESET = 0, 1, 2
+stats = {"accepted": 0, "rejected": 0, "resets": 0}   # process-wide tile counters (the reference has none)
+_stats_lock = threading.Lock()
+
+
+def _count(key: str) -> None:
+    with _stats_lock:
+        stats[key] += 1
+
+
+def submit_workload_ex(addr: str, port: int, workload: Workload, out: np.ndarray,
+                       timeout: Optional[float] = None) -> Tuple[int, int]:
+    """Second connection of WorkerCUDA.py:148-172.  Returns (status, payload bytes handed to the socket):
+    SUBMIT_REJECTED (0x21), SUBMIT_ACCEPTED (0x20 and every byte sent) or SUBMIT_RESET (0x20, then the
+    server reset the connection mid-payload)."""
     payload = memoryview(np.ascontiguousarray(out, dtype=np.uint8)).cast("B")
     if len(payload) != CHUNK_BYTES:
         raise ValueError(f"tile payload must be {CHUNK_BYTES} bytes, got {len(payload)}")
@@ -139,18 +155,45 @@ def submit_workload(addr: str, port: int, workload: Workload, out: np.ndarray,
         sock.sendall(struct.pack("<BIIII", RESPONSE_CODE, *workload))
         response = _recv_exact(sock, 1)[0]
         if response == WORKLOAD_REJECT_CODE:
-            return False
+            _count("rejected")
+            return SUBMIT_REJECTED, 0
         if response != WORKLOAD_ACCEPT_CODE:
             raise Exception("Unknown response code to request: " + str(response))  # WorkerCUDA.py:165-166
+        sent = 0
         try:
-            sock.sendall(payload)  # exactly 16 777 216 raw bytes, no header (WorkerCUDA.py:168)
+            while sent < CHUNK_BYTES:  # exactly 16 777 216 raw bytes, no header (WorkerCUDA.py:168)
+                sent += sock.send(payload[sent:])
         except (ConnectionResetError, BrokenPipeError):
             # The reference server reads the payload with ONE Socket.Receive (Distributer.cs:416) and
             # then closes; with unread bytes in flight that close is a TCP reset.  By then it has
-            # already marked the tile completed (:422-423).  The reference worker's single
-            # `sock.send` never notices; neither must a drop-in.
-            pass
-    return True
+            # already marked the tile completed (:422-423), and the reference worker's single
+            # `sock.send` never notices.  A server that died mid-transfer looks exactly the same from
+            # here, so the event is reported to the caller (and counted) instead of being swallowed.
+            _count("resets")
+            return SUBMIT_RESET, sent
+    _count("accepted")
+    return SUBMIT_ACCEPTED, sent
+
+
+def submit_workload(addr: str, port: int, workload: Workload, out: np.ndarray,
+                    timeout: Optional[float] = None) -> bool:
+    """True == accepted (0x20), False == rejected (0x21).  A reset after 0x20 counts as accepted, as it
+    does for the reference worker (see submit_workload_ex, which also says how much was sent)."""
+    return submit_workload_ex(addr, port, workload, out, timeout)[0] != SUBMIT_REJECTED
+
+
+def _log_submit(status: int, sent: int, log: Callable[..., None]) -> None:
+    if status == SUBMIT_ACCEPTED:
+        log("Response accepted")
+        log("Sent response")
+    elif status == SUBMIT_RESET:
+        log("Response accepted")
+        log(f"WARNING: connection reset by the server after {sent} of {CHUNK_BYTES} payload bytes. The reference "
+            "Distributer reads the payload with a single Receive and then closes (Distributer.cs:416-423), which "
+            "resets a still-sending client although the tile is already marked complete; a server that died "
+            "looks the same -- then the tile stays leased until its 1 h lease expires (Distributer.cs:22).")
+    else:
+        log("Response rejected")
 
 
 def do_workload_single(addr: str, port: int, compute: Optional[ComputeFn] = None,
@@ -168,39 +211,110 @@ def do_workload_single(addr: str, port: int, compute: Optional[ComputeFn] = None
     log("Calculation complete (%.1f ms)" % ((time.perf_counter() - t0) * 1e3))
     if compute is None and "default" in _last_stats:
         log(describe_stats(_last_stats["default"]))
-    if submit_workload(addr, port, workload, out):
-        log("Response accepted")
-        log("Sent response")
-    else:
-        log("Response rejected")
+    status, sent = submit_workload_ex(addr, port, workload, out)
+    _log_submit(status, sent, log)
     log("Process complete")
     return True
 
 
+def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[..., None] = print,
+                  max_tiles: Optional[int] = None, senders: int = 2, device=None,
+                  take: Optional[Callable[[], bool]] = None) -> int:
+    """One GPU, the protocol of do_workload_single, three stages overlapped:
+
+        lease tile n+1  |  GPU: tile n (slot n%2) -- D2H of tile n-1 overlaps it  |  sender thread(s): tile n-1
+
+    Per tile the wire sees exactly the reference's two exchanges (WorkerCUDA.py:115-134 and :148-172);
+    only their timing overlaps with other tiles', which the Distributer allows (any connection may
+    return any leased tile).  The device is driven from this thread only (an mbk_ctx is not
+    thread-safe); sender threads touch sockets and pinned host buffers.  `senders + 2` pinned 16 MiB
+    buffers circulate; a tile is submitted to the GPU only when a buffer is free, so a slow server
+    back-pressures the lease rate instead of growing a queue.  Ends when the server answers 0x11 or after
+    `max_tiles`; returns the number of tiles sent (accepted, incl. resets)."""
+    import queue
+    from .device import MandelbrotDevice
+    own = device is None
+    dev = device if device is not None else MandelbrotDevice(device_index)
+    nbuf = senders + 2
+    free: "queue.Queue" = queue.Queue()
+    for _ in range(nbuf):
+        free.put(dev.pinned_empty((CHUNK_BYTES,), np.uint8))
+    outbox: "queue.Queue" = queue.Queue()
+    errors: List[BaseException] = []
+    sent_ok = [0]
+
+    def sender() -> None:
+        while True:
+            item = outbox.get()
+            if item is None:
+                return
+            workload, buf, st = item
+            try:
+                status, nsent = submit_workload_ex(addr, port, workload, buf)
+                log(f"{workload}: " + describe_stats(st))
+                _log_submit(status, nsent, log)
+                if status != SUBMIT_REJECTED:
+                    with _stats_lock:
+                        sent_ok[0] += 1
+            except BaseException as e:
+                errors.append(e)
+            finally:
+                free.put(buf)
+
+    threads = [threading.Thread(target=sender, daemon=True) for _ in range(max(1, senders))]
+    for t in threads:
+        t.start()
+    inflight: List[Optional[tuple]] = [None, None]   # per device slot: (workload, buffer)
+    leased = 0
+    slot = 0
+    try:
+        more = True
+        while more or any(inflight):
+            if more and not errors and (max_tiles is None or leased < max_tiles) and (take is None or take()):
+                workload = request_workload(addr, port)
+                if workload is None:
+                    log("No workload was available, ending program")
+                    more = False
+            else:
+                workload, more = None, False
+            # retire the tile that occupies the slot we are about to reuse (or drain at the end)
+            if inflight[slot] is not None:
+                w_old, b_old = inflight[slot]
+                st = dev.wait(slot)
+                inflight[slot] = None
+                outbox.put((w_old, b_old, st))
+            if workload is not None:
+                log("Workload received:", workload)
+                buf = free.get()
+                dev.submit_datachunk(slot, *workload, buf)
+                inflight[slot] = (workload, buf)
+                leased += 1
+            slot ^= 1
+    finally:
+        for _ in threads:
+            outbox.put(None)
+        for t in threads:
+            t.join()
+        if own:
+            dev.close()
+    if errors:
+        raise errors[0]
+    return sent_ok[0]
+
+
 def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
              make_compute: Optional[Callable[[int], ComputeFn]] = None,
-             log: Callable[..., None] = print, max_tiles: Optional[int] = None) -> List[int]:
-    """One feeder thread per GPU, each looping do_workload_single until the Distributer answers
-    0x11.  Returns the number of tiles each feeder completed.  `make_compute(device_index)` builds
-    the per-thread compute function (default: a MandelbrotDevice per GPU)."""
+             log: Callable[..., None] = print, max_tiles: Optional[int] = None, senders: int = 2) -> List[int]:
+    """One feeder thread per GPU until the Distributer answers 0x11.  Each feeder is `run_pipelined`
+    (lease / compute / send overlapped, two tiles in flight on its GPU); with `make_compute(device_index)`
+    -- a per-thread compute function, used by the CPU tests -- it is the serial do_workload_single loop.
+    Returns the number of tiles each feeder completed."""
     if devices is None:
         from .device import device_count
         devices = list(range(device_count()))
         if not devices:
             raise RuntimeError("no gfx950 GPU visible and no CPU fallback exists")
 
-    def default_make(dev_index: int) -> ComputeFn:
-        from .device import MandelbrotDevice
-        dev = MandelbrotDevice(dev_index)
-        pinned = dev.pinned_empty((CHUNK_BYTES,), np.uint8)
-
-        def compute(level, mrd, ir, ii):
-            out, _, st = dev.datachunk(level, mrd, ir, ii, out_bytes=pinned)
-            log(f"[gpu{dev_index}]", describe_stats(st))
-            return out
-        return compute
-
-    make = make_compute or default_make
     done = [0] * len(devices)
     errors: List[BaseException] = []
     budget = [max_tiles]
@@ -216,11 +330,14 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
             return True
 
     def feeder(slot: int, dev_index: int) -> None:
+        tag = lambda *a: log(f"[gpu{dev_index}]", *a)
         try:
-            compute = make(dev_index)
+            if make_compute is None:
+                done[slot] = run_pipelined(addr, port, dev_index, log=tag, senders=senders, take=take)
+                return
+            compute = make_compute(dev_index)
             while take():
-                if not do_workload_single(addr, port, compute=compute,
-                                          log=lambda *a: log(f"[gpu{dev_index}]", *a)):
+                if not do_workload_single(addr, port, compute=compute, log=tag):
                     break
                 done[slot] += 1
         except BaseException as e:  # surfaced to the caller below
@@ -248,13 +365,12 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     devices = [int(x) for x in argv[2].split(",")] if len(argv) >= 3 else None
     if devices is None:
         from .device import device_count
-        n = device_count()
-        devices = list(range(n))
-    if len(devices) <= 1:
-        while do_workload_single(addr, port):
-            pass
-    else:
-        run_farm(addr, port, devices)
+        devices = list(range(device_count()))
+    # every listed GPU gets its own pipelined feeder (an explicit single index -- `worker ADDR PORT 3` --
+    # runs on THAT GPU; round 1 sent it to GPU 0)
+    run_farm(addr, port, devices)
+    log_stats = dict(stats)
+    print("tiles:", log_stats)
 
 
 if __name__ == "__main__":

@@ -181,6 +181,10 @@ int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, ui
 int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
                          uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts);
 int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats);
+/* The same for a generic view / window (the multi-GPU shard unit is a row band of a view): enqueue on
+ * `slot`, results land in h_counts / h_bytes (either may be NULL according to flags) after mbk_wait. */
+int mbk_view_submit(mbk_ctx *ctx, int slot, const mbk_view *view, uint32_t mrd, uint32_t flags,
+                    int32_t *h_counts, uint8_t *h_bytes);
 
 /* Codec codes of DataChunkSerializer.cs (Raw :20, RLE :54). */
 #define MBK_CODEC_RAW 0x00u
@@ -209,13 +213,21 @@ enum mbk_option {
     MBK_OPT_EXACT_STEPS,   /* scan/group: steps tested one by one before the grouped test takes over: 0..4096 [8] */
     MBK_OPT_PROBE_STEPS,   /* asm/group: depth of the heavy-first probe: 2..65536 [32] */
     MBK_OPT_SCAN_STEPS,    /* scan: grouped steps pass 1 runs after the exact ones, a multiple of 16: 0..65536 [16] */
-    MBK_OPT_SCAN_WAVES,    /* scan: resident waves per SIMD of both passes: 1..[8] */
+    MBK_OPT_SCAN_WAVES,    /* scan: resident waves per SIMD of pass 1: 1..[8] */
+    MBK_OPT_SCAN_XCD_MAP,  /* scan: XCD-aware block-column order in pass 1 (a 128-byte output line is completed in one L2):
+                              0 off, 1 on, [2] on when the quantised bytes are written */
+    MBK_OPT_SCAN_COL_PERIOD, /* scan: sweeps a pass-1 wave stays in one block column before jumping to a far one: 0 (never) .. 65536 [4] */
+    MBK_OPT_HEAVY_SHARE,   /* default kernel: share of heavy blocks (x 65536) in the previous launch on the stream above
+                              which the next one uses "group" instead of "scan": 0..65536 [655 = 1 %] */
     MBK_OPT_RF_LIVEMIN,    /* refill: refill when this many lanes or fewer are live: 0..63 [48] */
     MBK_OPT_RF_PATIENCE,   /* refill: steps between forced refill checks: 16..2^20 [256] */
     MBK_OPT_RF_BATCH,      /* refill: blocks per queue pop: 1..64 [1] */
     MBK_OPT_RF_WAVES,      /* refill: resident waves per SIMD: 1..[8] */
     MBK_OPT_COUNT_
 };
+/* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
+ * four scan-path kernels, in single-wave workgroups per CU: +0 f64 scan, +1 f64 heavy, +2 f32 scan, +3 f32 heavy. */
+#define MBK_INFO_SCAN_WG_PER_CU 100
 int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value);
 int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value);
 

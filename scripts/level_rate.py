@@ -9,6 +9,9 @@ from distributedmandelbrot_amd import MandelbrotDevice
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 mrd = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 dev = MandelbrotDevice(0)
+for item in sys.argv[3:]:                      # library options, e.g. heavy_share=0 (always "group") / 65536 (always "scan")
+    k, _, v = item.partition("=")
+    dev.set_option(k, int(v))
 pin = dev.pinned_empty((16777216,), np.uint8)
 dev.datachunk(level, mrd, 0, 0, out_bytes=pin)  # warm-up
 ks, ds, its, never, imm, rle = [], [], 0, 0, 0, 0

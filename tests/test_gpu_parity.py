@@ -390,7 +390,8 @@ def test_smooth_buffer_survives_serialize_last(gpu, oracle):
 
 OPTION_MATRIX = [
     ("scan", {"exact_steps": 0}), ("scan", {"exact_steps": 3}), ("scan", {"scan_steps": 0}),
-    ("scan", {"scan_steps": 48}), ("scan", {"scan_waves": 1}), ("scan", {"scan_waves": 3, "exact_steps": 16}),
+    ("scan", {"scan_steps": 48}), ("scan", {"scan_waves": 1}), ("scan", {"scan_xcd_map": 0}), ("scan", {"scan_xcd_map": 1}),
+    ("scan", {"scan_col_period": 0}), ("scan", {"scan_col_period": 1, "scan_xcd_map": 0}), ("scan", {"scan_waves": 3, "exact_steps": 16}),
     ("group", {"exact_steps": 0}), ("group", {"exact_steps": 5}), ("group", {"group_steps": 4}),
     ("group", {"waves_per_wg": 2}), ("group", {"waves_per_wg": 4, "order": 1}), ("group", {"order": 0}),
     ("group", {"order": 1}), ("group", {"probe_steps": 2}), ("asm", {"waves_per_wg": 4, "order": 0}),
@@ -459,3 +460,50 @@ def test_launches_on_many_streams_have_private_scratch(gpu, oracle):
     torch.cuda.synchronize()
     for o in outs:
         assert np.array_equal(o.cpu().numpy().reshape(768, 1024), oc)
+
+
+def test_render_view_into_pinned_image_two_slots(gpu, oracle):
+    """render_view DMAs each band straight into its rows of a caller-supplied pinned image, two bands in
+    flight on the device (mbk_view_submit / mbk_wait); the same image through plain numpy memory too."""
+    from distributedmandelbrot_amd.sharding import render_view
+    view, mrd = View(-0.755, 0.10, 0.02, 0.02, 1024, 1000), 900
+    oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, 1024, 1000, mrd)
+    pc, pb = gpu.pinned_empty((1000, 1024), np.int32), gpu.pinned_empty((1000, 1024), np.uint8)
+    pc[...] = -1
+    c, b, per = render_view([gpu], view, mrd, band_rows=72, out_counts=pc, out_bytes=pb)
+    assert c is pc and b is pb and np.array_equal(pc, oc) and np.array_equal(pb, ob)
+    assert per[0]["bands"] == 14 and per[0]["pixel_iterations"] == total
+    c2, b2, _ = render_view([gpu], view, mrd, band_rows=128, kernel="group")
+    assert np.array_equal(c2, oc) and np.array_equal(b2, ob)
+
+
+def test_pipelined_worker_on_gpu_against_fake_distributer(gpu, golden):
+    """worker.run_pipelined on the real device: lease / compute / send overlapped, two tiles in flight;
+    the server ends up with the reference-made golden bytes for every tile."""
+    from distributedmandelbrot_amd import worker
+    from fake_distributer import FakeDistributer
+    with FakeDistributer([(4, 256)]) as srv:
+        n = worker.run_pipelined("127.0.0.1", srv.port, device=gpu, log=lambda *a: None, senders=2, max_tiles=7)
+        assert n == 7 and srv.wait_completed(7, timeout=60)
+        for key, w in (("4_256_0_0", (4, 256, 0, 0)), ("4_256_1_2", (4, 256, 1, 2))):
+            assert hashlib.sha256(srv.completed[w].tobytes()).hexdigest() == str(golden[f"full/{key}/bytes_sha256"])
+
+
+def test_default_kernel_follows_the_heavy_share_hint(oracle):
+    """The default kernel is chosen from what the previous launch on the stream reported (pinned-memory hint,
+    no host round trip): light tiles -> "scan", heavy tiles -> "group".  Whatever it picks, and in whatever
+    order tiles arrive, results are bit-exact; a threshold of 0 / 65536 forces either path."""
+    from distributedmandelbrot_amd import MandelbrotDevice
+    heavy = (View(-0.2, -0.1, 0.2, 0.2, 1024, 1024), 300)      # inside the cardioid: every block heavy
+    light = (View(-2.0, -2.0, 1.0, 1.0, 1024, 1024), 300)      # far exterior: nothing deferred
+    mixed = (View(-2.0, -1.5, 3.0, 3.0, 1024, 1024), 300)
+    want = {k: oracle.view(v.start_r, v.start_i, v.range_r, v.range_i, v.width, v.height, m, want_bytes=False)[0]
+            for k, (v, m) in (("heavy", heavy), ("light", light), ("mixed", mixed))}
+    cases = {"heavy": heavy, "light": light, "mixed": mixed}
+    for share in (655, 0, 65536):
+        with MandelbrotDevice(0) as dev:
+            dev.set_option("heavy_share", share)
+            for name in ["light", "heavy", "heavy", "light", "mixed", "mixed", "heavy", "light", "light"]:
+                v, m = cases[name]
+                c, _, _ = dev.compute_view(v, m, want_bytes=False)
+                assert np.array_equal(c, want[name]), (share, name)

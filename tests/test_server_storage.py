@@ -5,6 +5,7 @@ import os
 import socket
 import struct
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -144,3 +145,32 @@ def test_gpu_tiles_through_the_whole_pipeline(tmp_path, gpu, oracle):
         assert np.array_equal(direct.load_chunk(level, ir, ii), want)
         if not want.any():
             assert e.type == TYPE_NEVER
+
+
+def test_duplicate_response_for_one_lease_is_rejected_while_first_is_arriving():
+    """Two responses for the same leased tile (an expired worker and its successor, or a retry): the
+    reference handles connections one at a time and accepts only the first (Distributer.cs:404-423); the
+    threaded stand-in must claim the lease atomically -- the second gets 0x21 even while the first
+    payload is still on the wire, and a failed transfer makes the lease live again."""
+    import socket
+    import struct
+    with Distributer([(1, 8)]) as dist:
+        w = worker.request_workload("127.0.0.1", dist.port)
+        a = socket.create_connection(("127.0.0.1", dist.port))
+        a.sendall(struct.pack("<BIIII", 0x01, *w))
+        assert a.recv(1) == bytes([0x20])
+        a.sendall(bytes(1000))                                   # payload in progress ...
+        assert worker.submit_workload("127.0.0.1", dist.port, w, np.zeros(CHUNK_BYTES, np.uint8)) is False
+        assert dist.rejected == [w] and dist.received == 0
+        a.close()                                                # ... and it never completes
+        for _ in range(200):
+            if dist.leases:
+                break
+            time.sleep(0.01)
+        assert [lw for lw, _ in dist.leases] == [w] and not dist.receiving   # lease restored
+        assert worker.submit_workload("127.0.0.1", dist.port, w, np.ones(CHUNK_BYTES, np.uint8)) is True
+        for _ in range(200):
+            if dist.received == 1:
+                break
+            time.sleep(0.01)
+        assert dist.received == 1 and dist.all_done()

@@ -21,12 +21,36 @@ class OracleDevice:
         self.oracle = oracle
         self.calls = 0
 
-    def compute_view(self, view, mrd, *, window=None, want_counts=True, want_bytes=True, kernel="default"):
+    def compute_view(self, view, mrd, *, window=None, want_counts=True, want_bytes=True, kernel="default",
+                     out_counts=None, out_bytes=None):
         self.calls += 1
         c, b, total = self.oracle.view(view.start_r, view.start_i, view.range_r, view.range_i,
                                        view.width, view.height, mrd, window=window, nthreads=1)
+        if out_counts is not None:
+            out_counts[...] = c
+        if out_bytes is not None:
+            out_bytes[...] = b
         return (c if want_counts else None, b if want_bytes else None,
                 TileStats(0.0, 0.0, total, int((c == 0).sum()), False, False))
+
+
+class TwoSlotOracleDevice(OracleDevice):
+    """Adds the asynchronous pair submit_view / wait (two slots) that render_view prefers."""
+
+    def __init__(self, oracle):
+        super().__init__(oracle)
+        self.pending = [None, None]
+        self.max_inflight = 0
+
+    def submit_view(self, slot, view, mrd, *, window=None, out_counts=None, out_bytes=None, kernel="default"):
+        assert self.pending[slot] is None, "slot reused before wait"
+        self.pending[slot] = (view, mrd, window, out_counts, out_bytes)
+        self.max_inflight = max(self.max_inflight, sum(p is not None for p in self.pending))
+
+    def wait(self, slot):
+        view, mrd, window, oc, ob = self.pending[slot]
+        self.pending[slot] = None
+        return self.compute_view(view, mrd, window=window, out_counts=oc, out_bytes=ob)[2]
 
 
 def test_make_bands_cover_exactly():
@@ -75,6 +99,18 @@ def test_render_view_over_fake_devices_equals_whole_view(oracle):
     assert np.array_equal(c, oc) and np.array_equal(b, ob)
     assert sum(p["bands"] for p in per) == 10 and sum(p["pixel_iterations"] for p in per) == total
     assert sum(d.calls for d in devs) == 10
+
+
+def test_render_view_two_slots_writes_bands_in_place(oracle):
+    """Two bands in flight per device, each landing directly in its rows of a caller-supplied image."""
+    view, mrd = View(-0.755, 0.10, 0.02, 0.02, 160, 203), 300
+    devs = [TwoSlotOracleDevice(oracle) for _ in range(2)]
+    counts = np.full((203, 160), -1, np.int32)
+    c, b, per = render_view(devs, view, mrd, band_rows=24, want_bytes=False, out_counts=counts)
+    oc, _, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, 160, 203, mrd)
+    assert c is counts and b is None and np.array_equal(counts, oc)
+    assert sum(p["bands"] for p in per) == 9 and sum(p["pixel_iterations"] for p in per) == total
+    assert max(d.max_inflight for d in devs) == 2 and all(p is None for d in devs for p in d.pending)
 
 
 def test_bench_distributed_path_gloo_world2():

@@ -144,3 +144,94 @@ def test_reference_faithful_single_receive_mode_documents_the_defect():
         got = int([l for l in srv.log if l.startswith("single receive")][0].split()[3])
         assert 0 < got <= CHUNK_BYTES
         assert np.array_equal(data[:got], pattern_compute(*w)[:got])
+
+
+class _FakeDevice:
+    """Stands in for MandelbrotDevice in run_pipelined (CPU tests): two slots, pattern bytes as 'compute'."""
+
+    def __init__(self):
+        from distributedmandelbrot_amd.device import TileStats
+        self._stats = TileStats
+        self.slots = [None, None]
+        self.submitted = []
+        self.max_inflight = 0
+
+    def pinned_empty(self, shape, dtype):
+        return np.empty(shape, dtype)
+
+    def submit_datachunk(self, slot, level, mrd, ir, ii, out_bytes):
+        assert self.slots[slot] is None, "slot reused before wait"
+        self.slots[slot] = ((level, mrd, ir, ii), out_bytes)
+        self.submitted.append((level, mrd, ir, ii))
+        self.max_inflight = max(self.max_inflight, sum(x is not None for x in self.slots))
+
+    def wait(self, slot):
+        w, buf = self.slots[slot]
+        buf[:] = pattern_compute(*w)
+        self.slots[slot] = None
+        return self._stats(0.1, 0.1, 1000, 0, False, False, 5)
+
+    def close(self):
+        pass
+
+
+def test_pipelined_worker_same_wire_every_tile_once():
+    """run_pipelined: lease / compute / send overlapped with two tiles in flight on the device; per tile
+    the wire carries the reference's two exchanges, and every tile is completed exactly once."""
+    with FakeDistributer([(3, 16), (1, 8)]) as srv:
+        dev = _FakeDevice()
+        n = worker.run_pipelined("127.0.0.1", srv.port, device=dev, log=QUIET, senders=2)
+        assert srv.wait_completed(10)
+        assert n == 10 and len(srv.completed) == 10 and not srv.rejected
+        assert sorted(dev.submitted) == sorted(srv.completed) and len(set(dev.submitted)) == 10
+        assert dev.max_inflight == 2                      # both device slots were really used
+        for w, data in srv.completed.items():
+            assert np.array_equal(data, pattern_compute(*w))
+        assert not [l for l in srv.log if "error" in l or "unknown" in l], srv.log
+
+
+def test_pipelined_worker_respects_max_tiles_and_threaded_server():
+    from distributedmandelbrot_amd.server import Distributer
+    with Distributer([(4, 16)]) as dist:
+        dev = _FakeDevice()
+        n = worker.run_pipelined("127.0.0.1", dist.port, device=dev, log=QUIET, senders=3, max_tiles=7)
+
+        def settled(k):        # the client returns when its last byte is queued; the server may lag
+            import time
+            for _ in range(500):
+                if dist.received == k:
+                    return True
+                time.sleep(0.01)
+            return False
+        assert n == 7 and settled(7)
+        n2 = worker.run_pipelined("127.0.0.1", dist.port, device=_FakeDevice(), log=QUIET)
+        assert n2 == 9 and settled(16) and dist.all_done()
+
+
+def test_reset_mid_payload_is_reported_and_counted():
+    """A server that stops reading after one Receive (the reference defect, Distributer.cs:416) resets the
+    still-sending client: the worker reports SUBMIT_RESET with the bytes it got out, counts it, logs a
+    warning -- and, like the reference worker, carries on."""
+    before = dict(worker.stats)
+    with FakeDistributer([(1, 8)], faithful_single_receive=True) as srv:
+        w = worker.request_workload("127.0.0.1", srv.port)
+        status, sent = worker.submit_workload_ex("127.0.0.1", srv.port, w, pattern_compute(*w))
+        assert srv.wait_completed(1)
+    assert status in (worker.SUBMIT_RESET, worker.SUBMIT_ACCEPTED)
+    if status == worker.SUBMIT_RESET:
+        assert 0 < sent < CHUNK_BYTES and worker.stats["resets"] == before["resets"] + 1
+        lines = []
+        worker._log_submit(status, sent, lambda *a: lines.append(" ".join(str(x) for x in a)))
+        assert any("connection reset by the server after" in l for l in lines)
+    else:
+        assert sent == CHUNK_BYTES and worker.stats["accepted"] == before["accepted"] + 1
+
+
+def test_main_honours_an_explicit_single_device(monkeypatch):
+    """`worker ADDR PORT 3` must run on GPU 3 (round 1 sent every single-device invocation to GPU 0)."""
+    seen = {}
+    monkeypatch.setattr(worker, "run_farm", lambda addr, port, devices, **kw: seen.update(addr=addr, port=port, devices=devices) or [0])
+    worker.main(["10.0.0.1", "59010", "3"])
+    assert seen == {"addr": "10.0.0.1", "port": 59010, "devices": [3]}
+    worker.main(["h", "1", "0,2,5"])
+    assert seen["devices"] == [0, 2, 5]
