@@ -24,9 +24,9 @@ are count if count > 0 else mrd-1, summed from the kernel's own output (SURVEY.m
 `roofline`: the path is bound by the fp64 vector-ALU issue rate (not HBM, not MFMA -- FMA contraction
 is forbidden by bit-exactness): achieved = 8 algorithmic flops per pixel-iteration / average
 launch duration (HIP events on the launch stream); peak = CUs x 4 SIMD x 16 fp64 lanes x 2 flop x
-clock (78.6 TFLOP/s on MI355X).  Under parity the default kernel needs 6.25 fp64-rate VALU issue
-slots per 8 flops (6 arithmetic ops per step + one add and one compare per 8 steps), so the flops
-fraction cannot exceed 8/12.5 = 0.64; `valu_slot_util` (= issue slots actually spent per
+clock (78.6 TFLOP/s on MI355X).  Under parity the default kernel needs 6.125 fp64-rate VALU issue
+slots per 8 flops (6 arithmetic ops per step + one add and one compare per 16 steps), so the flops
+fraction cannot exceed 8/12.25 = 0.653; `valu_slot_util` (= issue slots actually spent per
 pixel-iteration over the 39.3 T lane-op/s issue peak at 2.4 GHz) is the "how close to the metal"
 figure.  `traffic` is HBM bytes per launch from separate `rocprofv3 --pmc` passes of this same command
 (committed under profiles/, see `traffic_source`); counters cannot be read from inside the run.
@@ -67,8 +67,9 @@ DEFAULT_PRECISION = {"cfg4": "f32"}
 SMOOTH_WORKLOADS = {"cfg5"}
 FLOPS_PER_PIXEL_ITER = 8        # 4 mul + 4 add/sub with the squares shared
 # fp64-rate VALU issue slots each kernel spends per pixel-iteration (v_cmp costs a full slot on gfx950):
-#   per-step test: 3 mul + 3 add + 1 fma + 1 v_cmp = 8;  grouped test (default): 6 + 2 per 8 steps = 6.25
-VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.25, "scan": 6.25, "group": 6.25, "refill": 6.25, "asm": 8.0, "simple": 8.0}
+#   per-step test: 3 mul + 3 add + 1 fma + 1 v_cmp = 8;  grouped test: 6 + 2 per group = 6.25 (8-step groups,
+#   kernel "refill" and option group_steps=8) or 6.125 (16-step groups: the default for interior blocks)
+VALU_SLOTS_PER_PIXEL_ITER = {"default": 6.125, "scan": 6.125, "group": 6.125, "refill": 6.25, "asm": 8.0, "simple": 8.0}
 # default (steps, warmup) per workload: enough launches for a steady clock, a few seconds at most
 DEFAULT_STEPS = {"cfg1": (400, 50), "cfg2": (400, 50), "chunk_l1": (400, 50), "inset": (60, 8), "exterior": (400, 50),
                  "cfg3": (20, 3), "cfg4": (3, 1), "cfg5": (40, 5)}
@@ -388,6 +389,8 @@ def main():
         per_gpu_iters = iters_per_step / (world if bands_mode else 1)
         achieved_tflops = FLOPS_PER_PIXEL_ITER * per_gpu_iters / avg_kernel_s / 1e12
         slots = VALU_SLOTS_PER_PIXEL_ITER.get(args.kernel, 8.0)
+        if args.kernel in ("default", "scan", "group") and options.get("group_steps", 16) != 16:
+            slots = 6.25 if options["group_steps"] == 8 else 6.5
         out_bytes = npix * (12 if smooth else 4)
         traffic, traffic_source = pmc_traffic(args.workload, args.kernel) if args.precision == "f64" and not options else (None, None)
         metric = "G pixel-iterations/s on 4096^2 tile, max_iter=1000 fp64"

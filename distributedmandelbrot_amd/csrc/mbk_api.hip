@@ -265,6 +265,8 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, 0, stream, a);
     else if (kernel == MBK_KERNEL_ASM)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, 0, stream, a);
+    else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 16)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16>), grid, block, 0, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 8)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, 0, stream, a);
     else
@@ -426,6 +428,7 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, hipStream_t stream)
     s.ranks2 = std::max(s.ranks2, std::min(qcap, (cus * 32u + mbk::kScanQueues - 1u) / mbk::kScanQueues));
     if (s.ranks2 == 0u) s.ranks2 = 1u;
     s.hint_out = sc->h_hint;
+    s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] == 16u ? 1u : 0u;
     const uint32_t w2 = mbk::kScanQueues * s.ranks2;
     a.ring_possible = window_may_touch_ring(a, sizeof(T) == 4 ? 2e-3 : 1e-6) ? 1u : 0u;
     hipLaunchKernelGGL(mbk::tile_scan_kernel<T>, dim3(w1), dim3(64), 0, stream, a, s);
@@ -588,7 +591,7 @@ int mbk_create(int device, mbk_ctx **out)
     if (!ctx) return fail(nullptr, MBK_ERR_NOMEM, "out of host memory");
     ctx->device = device;
     static const uint32_t kDefaults[MBK_OPT_COUNT_] = {
-        /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 8u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
+        /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_STEPS */ 16u, /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 2u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
@@ -934,7 +937,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
     switch (option) {
         case MBK_OPT_ORDER: ok = value <= 2u; break;
         case MBK_OPT_WAVES_PER_WG: ok = value == 1u || value == 2u || value == 4u; break;
-        case MBK_OPT_GROUP_STEPS: ok = value == 4u || value == 8u; break;
+        case MBK_OPT_GROUP_STEPS: ok = value == 4u || value == 8u || value == 16u; break;
         case MBK_OPT_EXACT_STEPS: ok = value <= 4096u; break;
         case MBK_OPT_PROBE_STEPS: ok = value >= 2u && value <= 65536u; break;
         case MBK_OPT_SCAN_STEPS: ok = value % 16u == 0u && value <= 65536u; break;

@@ -196,8 +196,17 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
         const T c2 = cr * cr + ci * ci;
         const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
         const bool risky = __any(c2 > (T)4 - margin && c2 < (T)4 + margin) != 0;
-        count = risky ? escape_count_asm<true>(cr, ci, p.mrd, &m)
-                      : escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd, &m, p.exact_steps);
+        if (risky) {
+            count = escape_count_asm<true>(cr, ci, p.mrd, &m);
+        } else if (kGroup == 16) {
+            // 16-step groups (6.125 issue slots per step) only where the test hardly ever trips: the blocks the
+            // heavy-first probe put at the front of the dispatch order (interior of the set); 8 elsewhere
+            const bool long_groups = !p.order || blockIdx.x < p.order[gridDim.x];   // wave-uniform
+            count = long_groups ? escape_count_group<16>(cr, ci, p.mrd, &m, p.exact_steps)
+                                : escape_count_group<8>(cr, ci, p.mrd, &m, p.exact_steps);
+        } else {
+            count = escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd, &m, p.exact_steps);
+        }
     } else {
         count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd, &m);
     }

@@ -81,6 +81,7 @@ struct ScanArgs {
     uint32_t col_jump;      // ... then it moves this many block columns to the right (mod blocks_x)
     uint32_t xcd_map;       // pass 1: 1 = XCD-aware block-column permutation (needs blocks_x % 32 == 0, stride_bx == 0)
     uint32_t ranks2;        // pass 2: elements per list covered by the grid (grid = 64 * ranks2)
+    uint32_t long_groups;   // pass 2: 1 = dense blocks use 16-step groups (option group_steps == 16)
 };
 
 template <typename T>
@@ -254,7 +255,9 @@ __global__ __launch_bounds__(64) void tile_heavy_kernel(TileArgs p, ScanArgs s)
             const T ci = (T)scan_axis_value(p.im, p.row0 + lr);
             T zr = st.zr, zi = st.zi, a = zr * zr, bq = zi * zi, m = 0;
             int32_t cnt = 0;
-            escape_steps_group<8>(cr, ci, zr, zi, a, bq, m, cnt, s.scan_steps, total);
+            // dense blocks (interior): 16-step groups, 6.125 slots per step; the others: 8 (cheaper replays)
+            if (s.long_groups && i < len_d) escape_steps_tail<16>(cr, ci, zr, zi, a, bq, m, cnt, s.scan_steps, total);
+            else escape_steps_group<8>(cr, ci, zr, zi, a, bq, m, cnt, s.scan_steps, total);
             if (cnt > 0) store_results<T>(p, (size_t)(lr + p.out_row0) * p.out_pitch + lc + p.out_col0, cnt, m);
         }
     }

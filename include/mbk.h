@@ -209,7 +209,8 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
 enum mbk_option {
     MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] heavy-first list */
     MBK_OPT_WAVES_PER_WG,  /* asm/group: 8x8 blocks per workgroup: [1], 2, 4 */
-    MBK_OPT_GROUP_STEPS,   /* group: steps per grouped bailout test: 4, [8] */
+    MBK_OPT_GROUP_STEPS,   /* group / scan pass 2: steps per grouped bailout test: 4, 8, [16] (16 applies to the blocks
+                              classified as interior -- probe-heavy / dense --, the rest keep 8) */
     MBK_OPT_EXACT_STEPS,   /* scan/group: steps tested one by one before the grouped test takes over: 0..4096 [8] */
     MBK_OPT_PROBE_STEPS,   /* asm/group: depth of the heavy-first probe: 2..65536 [32] */
     MBK_OPT_SCAN_STEPS,    /* scan: grouped steps pass 1 runs after the exact ones, a multiple of 16: 0..65536 [16] */

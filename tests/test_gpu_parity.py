@@ -392,7 +392,8 @@ OPTION_MATRIX = [
     ("scan", {"exact_steps": 0}), ("scan", {"exact_steps": 3}), ("scan", {"scan_steps": 0}),
     ("scan", {"scan_steps": 48}), ("scan", {"scan_waves": 1}), ("scan", {"scan_xcd_map": 0}), ("scan", {"scan_xcd_map": 1}),
     ("scan", {"scan_col_period": 0}), ("scan", {"scan_col_period": 1, "scan_xcd_map": 0}), ("scan", {"scan_waves": 3, "exact_steps": 16}),
-    ("group", {"exact_steps": 0}), ("group", {"exact_steps": 5}), ("group", {"group_steps": 4}),
+    ("group", {"exact_steps": 0}), ("group", {"exact_steps": 5}), ("group", {"group_steps": 4}), ("group", {"group_steps": 8}), ("group", {"group_steps": 16, "order": 0}),
+    ("scan", {"group_steps": 8}),
     ("group", {"waves_per_wg": 2}), ("group", {"waves_per_wg": 4, "order": 1}), ("group", {"order": 0}),
     ("group", {"order": 1}), ("group", {"probe_steps": 2}), ("asm", {"waves_per_wg": 4, "order": 0}),
     ("refill", {"rf_livemin": 0}), ("refill", {"rf_livemin": 63, "rf_patience": 16}),
