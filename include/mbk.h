@@ -52,7 +52,7 @@ enum mbk_status {
 #define MBK_KERNEL_SIMPLE 0x100u /* one lane per pixel, compiler-scheduled loop, literal (2*zr)*zi form */
 #define MBK_KERNEL_ASM 0x200u    /* one lane per pixel, hand-scheduled gfx950 loop */
 #define MBK_KERNEL_REFILL 0x300u /* persistent waves with lane refill (deep-zoom divergence) */
-#define MBK_KERNEL_GROUP 0x400u  /* hand-scheduled loop, bailout tested once per 8 steps + exact replay; one workgroup per 8x8 block */
+#define MBK_KERNEL_GROUP 0x400u  /* hand-scheduled loop, bailout tested once per 16 (interior) / 8 steps + exact replay; one workgroup per 8x8 block */
 #define MBK_KERNEL_SCAN 0x500u   /* the same loops in two persistent passes: a chip-filling scan that finishes every block
                                     whose pixels escape early, then a work-queue pass over the deferred blocks */
 

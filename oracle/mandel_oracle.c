@@ -118,6 +118,56 @@ int32_t mbo_escape_f32(float cr, float ci, int32_t mrd)
     return 0;
 }
 
+/* What-if variant ("contraction sensitivity"): the same loop with the FMA contraction a
+ * CUDA toolchain applies by default to `a*b + c` patterns (numba -> NVVM, fmad on): the three
+ * expressions of WorkerCUDA.py:50-62 each lose one rounding --
+ *     z0*z0 - z1*z1   -> fma(z0, z0, -(z1*z1))
+ *     (2*z0)*z1 + c1  -> fma(2*z0, z1, c1)
+ *     z0*z0 + z1*z1   -> fma(z0, z0, z1*z1)
+ * This is NOT the parity target (the reference's source, read strictly, is); it exists only to count how
+ * many pixels of a tile would differ between this worker and a worker whose compiler contracted. */
+int32_t mbo_escape_contracted(double cr, double ci, int32_t mrd)
+{
+    double zr = cr, zi = ci;
+    for (int32_t n = 1; n < mrd; ++n) {
+        double b = zi * zi;
+        double t = fma(zr, zr, -b);
+        double w = 2.0 * zr;
+        double u = fma(w, zi, ci);
+        zr = t + cr;
+        zi = u;
+        double m1 = zi * zi;
+        double m = fma(zr, zr, m1);
+        if (m >= 4.0) return n;
+    }
+    return 0;
+}
+
+uint64_t mbo_view_contracted(double start_r, double start_i, double range_r, double range_i,
+                             uint32_t width, uint32_t height, int32_t mrd, int32_t *counts, int nthreads)
+{
+    double *xr = (double *)malloc(sizeof(double) * (width ? width : 1));
+    double *xi = (double *)malloc(sizeof(double) * (height ? height : 1));
+    mbo_axis(start_r, range_r, width, xr);
+    mbo_axis(start_i, range_i, height, xi);
+    uint64_t total = 0;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads) reduction(+ : total)
+#else
+    (void)nthreads;
+#endif
+    for (int64_t r = 0; r < (int64_t)height; ++r)
+        for (uint32_t c = 0; c < width; ++c) {
+            int32_t cnt = mbo_escape_contracted(xr[c], xi[r], mrd);
+            counts[(size_t)r * width + c] = cnt;
+            total += cnt > 0 ? (uint64_t)cnt : (uint64_t)(mrd > 1 ? mrd - 1 : 0);
+        }
+    free(xr);
+    free(xi);
+    return total;
+}
+
 /* BASELINE config 5 (NOT in the reference): continuous escape-time value at the reference's bailout.
  * Runs the reference loop, keeps |z|^2 of the escaping step, nu = n + 1 - log2(0.5 * ln |z_n|^2); 0 if the
  * pixel never escapes.  *count_out receives the integer escape index. */

@@ -59,6 +59,9 @@ class COracle:
         L.mbo_datachunk.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_int]
         L.mbo_datachunk.restype = C.c_uint64
+        L.mbo_view_contracted.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
+                                          C.c_int32, C.c_void_p, C.c_int]
+        L.mbo_view_contracted.restype = C.c_uint64
         L.mbo_max_threads.restype = C.c_int
         L.mbo_have_avx512.restype = C.c_int
         L.mbo_view_avx512.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
@@ -104,6 +107,12 @@ class COracle:
         self.lib.mbo_view_smooth(start_r, start_i, range_r, range_i, width, height, mrd,
                                  smooth.ctypes.data, counts.ctypes.data)
         return smooth, counts
+
+    def view_contracted(self, start_r, start_i, range_r, range_i, width, height, mrd, *, nthreads=0):
+        """Counts under default CUDA-style FMA contraction (see mbo_escape_contracted): a what-if, not the oracle."""
+        counts = np.empty((height, width), np.int32)
+        self.lib.mbo_view_contracted(start_r, start_i, range_r, range_i, width, height, mrd, counts.ctypes.data, nthreads)
+        return counts
 
     def have_avx512(self) -> bool:
         return bool(self.lib.mbo_have_avx512())

@@ -1,18 +1,27 @@
-"""End-to-end tile rate of the drop-in worker against the Python stand-in Distributer (loopback TCP).
-Run on the GPU box:  python scripts/worker_e2e.py [level] [mrd] [feeders]"""
-import sys, time, threading
+"""End-to-end tile rate of the drop-in worker against the threaded stand-in Distributer (loopback TCP):
+the reference's serial loop (do_workload_single) vs the pipelined feeder (run_pipelined: lease / compute / send
+overlapped, two tiles in flight on the GPU).  Run on the GPU box:
+    python scripts/worker_e2e.py [level] [mrd] [senders]"""
+import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
-from fake_distributer import FakeDistributer
 from distributedmandelbrot_amd import worker, MandelbrotDevice
-from distributedmandelbrot_amd.device import device_count
+from distributedmandelbrot_amd.server import Distributer
 
-level = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 mrd = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-feeders = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-ngpu = device_count()
-print(f"GPUs visible: {ngpu}; level {level} ({level*level} tiles), mrd {mrd}, feeders {feeders}")
-# kernel-only and kernel+D2H per tile
+senders = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+n = level * level
+QUIET = lambda *a: None
+
+
+def settle(dist, k, timeout=120.0):
+    end = time.time() + timeout
+    while dist.received < k and time.time() < end:
+        time.sleep(0.002)
+    return dist.received >= k
+
+
 dev = MandelbrotDevice(0)
 pin = dev.pinned_empty((worker.CHUNK_BYTES,), np.uint8)
 ks, ds = [], []
@@ -22,11 +31,26 @@ for ir in range(level):
         _, _, st = dev.datachunk(level, mrd, ir, ii, out_bytes=pin)
         ks.append(st.kernel_ms); ds.append(st.d2h_ms)
 t_compute = time.perf_counter() - t0
-print(f"compute only (pinned D2H): {level*level/t_compute:.1f} tiles/s; kernel ms mean {np.mean(ks):.3f} max {np.max(ks):.3f}; d2h ms mean {np.mean(ds):.3f}")
-dev.close()
-with FakeDistributer([(level, mrd)]) as srv:
+print(f"level {level} ({n} tiles), mrd {mrd}: compute only (pinned D2H) {n / t_compute:.1f} tiles/s; kernel ms mean {np.mean(ks):.3f} "
+      f"median {np.median(ks):.3f} max {np.max(ks):.3f}; d2h ms mean {np.mean(ds):.3f}")
+
+with Distributer([(level, mrd)]) as dist:          # serial reference-shaped loop on the same device
+    def compute(lv, m, ir, ii):
+        out, _, _ = dev.datachunk(lv, m, ir, ii, out_bytes=pin)
+        return out
     t0 = time.perf_counter()
-    done = worker.run_farm("127.0.0.1", srv.port, devices=[0] * feeders, log=lambda *a: None)
-    assert srv.wait_completed(level * level, timeout=120)
+    k = 0
+    while worker.do_workload_single("127.0.0.1", dist.port, compute=compute, log=QUIET):
+        k += 1
+    assert settle(dist, n)
     dt = time.perf_counter() - t0
-print(f"through the wire protocol (single-threaded stand-in Distributer, loopback): {level*level/dt:.1f} tiles/s ({dt/level/level*1e3:.1f} ms/tile), per feeder {done}")
+print(f"serial worker loop (WorkerCUDA.py:111-176 shape): {n / dt:.1f} tiles/s ({dt / n * 1e3:.2f} ms/tile)")
+
+for s in sorted({1, 2, senders}):
+    with Distributer([(level, mrd)]) as dist:
+        t0 = time.perf_counter()
+        done = worker.run_pipelined("127.0.0.1", dist.port, device=dev, log=QUIET, senders=s)
+        assert done == n and settle(dist, n)
+        dt = time.perf_counter() - t0
+    print(f"pipelined worker, {s} sender thread(s): {n / dt:.1f} tiles/s ({dt / n * 1e3:.2f} ms/tile); stats {dict(worker.stats)}")
+dev.close()
