@@ -92,7 +92,7 @@ def parse_args():
     ap.add_argument("--precision", default=None, choices=["f64", "f32"],
                     help="f32 = BASELINE cfg4's fp32 kernel variant (not in the reference); default f64, cfg4: f32")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
-                    help="library tuning option (include/mbk.h enum mbk_option), e.g. --opt scan_steps=32; repeatable")
+                    help="library tuning option (include/mbk.h enum mbk_option), e.g. --opt group_steps=8; repeatable")
     ap.add_argument("--outputs", default="counts", choices=["counts", "both"],
                     help="counts (default, the contract's workload): int32 escape indices. both: also the quantised "
                          "uint8 tile the worker sends (what a DataChunk launch writes), for kernel studies")

@@ -37,9 +37,8 @@ struct StreamScratch {
     size_t order_cap = 0;         // regions
     WorkQueues *d_queues = nullptr;  // kernel "refill"
     mbk::ScanCursors *d_cursors = nullptr;  // kernel "scan": two sets, used alternately
-    mbk::ScanEntry *d_entries = nullptr;
-    void *d_state = nullptr;
-    size_t scan_cap_blocks = 0;   // capacity of d_entries / d_state in blocks (state: 64 * 16 B each)
+    uint32_t *d_entries = nullptr;   // kernel "scan": the 64 todo lists (block ids)
+    size_t scan_cap_blocks = 0;      // their capacity, in ids
     unsigned scan_turn = 0;
     uint32_t *h_hint = nullptr;   // pinned, written by the kernels of the last launch on this stream:
                                   // [0] longest deferred list (scan pass 2), [1] share of heavy blocks x 65536
@@ -192,7 +191,6 @@ static void free_scratch(StreamScratch &sc)
     if (sc.d_queues) (void)hipFree(sc.d_queues);
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
-    if (sc.d_state) (void)hipFree(sc.d_state);
     if (sc.h_hint) (void)hipHostFree(sc.h_hint);
     sc = StreamScratch();
 }
@@ -354,87 +352,89 @@ static int launch_refill(mbk_ctx *ctx, const TileArgs &a, bool safe, hipStream_t
     return MBK_OK;
 }
 
-// Kernel "scan" (default): pass 1 over every 8x8 block with a chip-filling persistent grid, pass 2 over
-// the deferred blocks (mbk_scan.h).  Views that need the literal-doubling loop go to launch_blocks.
+// Kernel "scan": a persistent light pass over every 8x8 block, then one workgroup per block it listed as
+// unfinished (mbk_scan.h).  Launches the light pass cannot serve go to launch_blocks ("group").
 template <typename T>
-static int launch_scan_t(mbk_ctx *ctx, TileArgs a, hipStream_t stream)
+static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream)
 {
+    const bool f32 = sizeof(T) == 4;
     a.blocks_x = (a.ncols + 7u) / 8u;
-    const uint32_t by = (a.nrows + 7u) / 8u;
-    const uint64_t nblocks64 = (uint64_t)a.blocks_x * by;
-    const uint32_t nblocks = (uint32_t)nblocks64;  // <= 2^31 pixels / 1 -> fits (validate_view)
+    const uint32_t nby = (a.nrows + 7u) / 8u;
+    const uint32_t nblocks = a.blocks_x * nby;  // <= 2^31 / 64 (validate_view)
+    const uint32_t total_steps = a.mrd > 1 ? (uint32_t)a.mrd - 1u : 0u;
+    // Pass 1 is a persistent grid: exactly as many single-wave workgroups as are resident at once (a second
+    // round of a statically strided pass would double its time) -- what the occupancy query reports for the
+    // kernel, capped by the scan_waves option -- rounded down to whole block rows.
+    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+    const uint32_t per_cu = std::min<uint32_t>(4u * ctx->opt[MBK_OPT_SCAN_WAVES], (uint32_t)ctx->scan_occ[f32 ? 1 : 0][0]);
+    const uint32_t wmax = cus * per_cu;
+    if (safe || a.re.step_is_zero || a.im.step_is_zero || a.smooth != nullptr || (a.bytes && a.quant_wide) ||
+        total_steps < 4u || !(a.counts || a.bytes) || a.blocks_x > wmax)
+        return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+
+    mbk::ScanArgs s;
+    s.stride_by = std::min(wmax / a.blocks_x, nby);
+    const uint32_t w1 = s.stride_by * a.blocks_x;
+    // every list is fed by the waves with its index mod 64; a wave lists at most its own blocks
+    const uint32_t qcap = ((w1 + mbk::kScanQueues - 1u) / mbk::kScanQueues) * ((nby + s.stride_by - 1u) / s.stride_by);
     StreamScratch *sc = nullptr;
     int rc = get_scratch(ctx, stream, &sc);
     if (rc != MBK_OK) return rc;
-    const uint32_t qcap = (nblocks + mbk::kScanQueues - 1u) / mbk::kScanQueues;
-    const size_t need_blocks = (size_t)qcap * mbk::kScanQueues;
     if (!sc->d_cursors) {
         MBK_HIP(ctx, hipMalloc((void **)&sc->d_cursors, 2 * sizeof(mbk::ScanCursors)));
         // once per stream, ON that stream: hipMemset on the null stream does not order against a
-        // non-blocking stream (the first launch on a new stream raced with it and lost deferred blocks)
+        // non-blocking stream (the first launch on a new stream raced with it and lost listed blocks)
         MBK_HIP(ctx, hipMemsetAsync(sc->d_cursors, 0, 2 * sizeof(mbk::ScanCursors), stream));
         sc->scan_turn = 0;
     }
-    if (need_blocks > sc->scan_cap_blocks) {
-        if (sc->d_entries || sc->d_state) MBK_HIP(ctx, hipStreamSynchronize(stream));  // may still be in use
-        if (sc->d_entries) (void)hipFree(sc->d_entries);
-        if (sc->d_state) (void)hipFree(sc->d_state);
+    const size_t need = (size_t)qcap * mbk::kScanQueues;
+    if (need > sc->scan_cap_blocks) {
+        if (sc->d_entries) {
+            MBK_HIP(ctx, hipStreamSynchronize(stream));  // may still be in use
+            (void)hipFree(sc->d_entries);
+        }
         sc->d_entries = nullptr;
-        sc->d_state = nullptr;
         sc->scan_cap_blocks = 0;
-        MBK_HIP(ctx, hipMalloc((void **)&sc->d_entries, need_blocks * sizeof(mbk::ScanEntry)));
-        // state is sized for the wider type so that fp32 and fp64 launches can share it
-        MBK_HIP(ctx, hipMalloc(&sc->d_state, need_blocks * 64u * sizeof(mbk::ScanState<double>)));
-        sc->scan_cap_blocks = need_blocks;
+        MBK_HIP(ctx, hipMalloc((void **)&sc->d_entries, need * sizeof(uint32_t)));
+        sc->scan_cap_blocks = need;
     }
-    mbk::ScanArgs s;
     s.cur = sc->d_cursors + (sc->scan_turn & 1u);
     s.cur_next = sc->d_cursors + ((sc->scan_turn + 1u) & 1u);
     ++sc->scan_turn;
     s.entries = sc->d_entries;
-    s.state = sc->d_state;
     s.qcap = qcap;
     s.nblocks = nblocks;
-    s.scan_steps = a.exact_steps + ctx->opt[MBK_OPT_SCAN_STEPS];
-    // Pass 1 is a persistent grid: exactly as many single-wave workgroups as are resident at once (a second
-    // round of a statically strided pass would double its time) -- what the occupancy query reports for the
-    // kernel (7 waves per SIMD: it keeps ~100 kernel arguments and loop constants in SGPRs; capping them for
-    // an 8th wave costs 15 spills per block), capped by the scan_waves option.
-    const int f = sizeof(T) == 4 ? 1 : 0;
-    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-    const uint32_t per_cu = std::min<uint32_t>(4u * ctx->opt[MBK_OPT_SCAN_WAVES], (uint32_t)ctx->scan_occ[f][0]);
-    const uint32_t wmax = cus * per_cu;
-    uint32_t w1 = std::min(wmax, nblocks);
-    // pass 1: a whole number of block rows per sweep keeps a wave in one block column for col_period sweeps
-    // (the real coordinate is computed once per column) -- unless that would idle more than a quarter of the chip
-    if (a.blocks_x <= w1 && (w1 / a.blocks_x) * a.blocks_x * 4u >= w1 * 3u) w1 = (w1 / a.blocks_x) * a.blocks_x;
-    s.stride = w1;
-    s.stride_bx = w1 % a.blocks_x;
-    s.stride_by = w1 / a.blocks_x;
-    // XCD-aware column order: pays when the quantised bytes are written (8-byte row segments: the
-    // all-exterior DataChunk takes 63 us without it, 44 us with it), nothing for int32 counts alone
-    const uint32_t xm = ctx->opt[MBK_OPT_SCAN_XCD_MAP];
-    s.xcd_map = ((xm == 1u || (xm == 2u && a.bytes != nullptr)) && s.stride_bx == 0u && a.blocks_x % 32u == 0u) ? 1u : 0u;
+    // XCD-aware column order (profiles/microbench/light_path.hip: the 8x8 store pattern of a 4096^2 int32 tile
+    // takes 25.6 us in image order -- each 128-byte line is written by four XCDs -- and 12.9 us with it)
+    s.xcd_map = (ctx->opt[MBK_OPT_SCAN_XCD_MAP] != 0u && a.blocks_x % 32u == 0u) ? 1u : 0u;
     // column jump: ~5/16 of the width, a multiple of 32 columns when the XCD map is on (keeps its grouping)
     s.col_period = ctx->opt[MBK_OPT_SCAN_COL_PERIOD];
     if (s.xcd_map) s.col_jump = 32u * (((a.blocks_x / 32u) * 5u / 16u) | 1u);
     else s.col_jump = std::max(1u, a.blocks_x * 5u / 16u);
     if (s.col_jump >= a.blocks_x) s.col_jump = 0u, s.col_period = 0u;
-    // pass 2: 64 lists x (hint = longest list of the previous launch on this stream + 25 %)
-    // Never fewer workgroups than fill the chip (when the tile has that many blocks): a hint from a light
-    // tile followed by a heavy one would otherwise leave a few waves looping over whole lists.
+    s.fast_bx_end = a.ncols / 8u;
+    s.fast_by_end = std::min(a.nrows / 8u, a.im.n > a.row0 + 8u ? (a.im.n - a.row0 - 1u) / 8u : 0u);
+    s.qtab = 0u;
+    if (a.bytes && a.mrd > 0)
+        for (uint32_t k = 1; k <= 4u; ++k)
+            s.qtab |= (uint32_t)(((uint64_t)k * 256u + (uint32_t)a.mrd - 1u) / (uint32_t)a.mrd & 0xffu) << (8u * (k - 1u));
+    // pass 2: 64 lists x (hint = longest list of the previous launch on this stream + 25 %).  Never fewer
+    // workgroups than fill the chip (when the tile has that many blocks): a hint from a light tile followed by
+    // a heavy one would otherwise leave a few waves looping over whole lists.
     const uint32_t hint = sc->h_hint[0];
     s.ranks2 = hint == 0xffffffffu ? qcap : (uint32_t)std::min<uint64_t>(qcap, (uint64_t)hint + hint / 4u + 2u);
     s.ranks2 = std::max(s.ranks2, std::min(qcap, (cus * 32u + mbk::kScanQueues - 1u) / mbk::kScanQueues));
     if (s.ranks2 == 0u) s.ranks2 = 1u;
     s.hint_out = sc->h_hint;
     s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] == 16u ? 1u : 0u;
-    const uint32_t w2 = mbk::kScanQueues * s.ranks2;
-    a.ring_possible = window_may_touch_ring(a, sizeof(T) == 4 ? 2e-3 : 1e-6) ? 1u : 0u;
-    hipLaunchKernelGGL(mbk::tile_scan_kernel<T>, dim3(w1), dim3(64), 0, stream, a, s);
-    // pass 2 has work only if the loop can run past pass 1's depth
-    if ((uint64_t)a.mrd > (uint64_t)s.scan_steps + 1u)
-        hipLaunchKernelGGL(mbk::tile_heavy_kernel<T>, dim3(w2), dim3(64), 0, stream, a, s);
+    a.ring_possible = window_may_touch_ring(a, f32 ? 2e-3 : 1e-6) ? 1u : 0u;
+    if (a.counts && a.bytes)
+        hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, true>), dim3(w1), dim3(64), 0, stream, a, s);
+    else if (a.bytes)
+        hipLaunchKernelGGL((mbk::tile_light_kernel<T, false, true>), dim3(w1), dim3(64), 0, stream, a, s);
+    else
+        hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, false>), dim3(w1), dim3(64), 0, stream, a, s);
+    hipLaunchKernelGGL(mbk::tile_todo_kernel<T>, dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
     MBK_HIP(ctx, hipGetLastError());
     return MBK_OK;
 }
@@ -482,9 +482,6 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
         case MBK_KERNEL_SCAN: {
-            // rare views (tiny imaginary parts / numpy's step == 0 fallback) keep the one-workgroup-per-block path
-            if (safe || a.re.step_is_zero || a.im.step_is_zero)
-                return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
             // Default = whichever of the two was the better choice for the PREVIOUS launch on this stream
             // (both leave the share of heavy blocks in pinned memory; no host round trip, and a stale or
             // wrong hint only costs time).  With more than ~1 % of the blocks heavy the tile is bound by
@@ -499,7 +496,7 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
                 if (share != 0xffffffffu && share > ctx->opt[MBK_OPT_HEAVY_SHARE])
                     return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
             }
-            return f32 ? launch_scan_t<float>(ctx, a, stream) : launch_scan_t<double>(ctx, a, stream);
+            return f32 ? launch_scan_t<float>(ctx, a, safe, stream) : launch_scan_t<double>(ctx, a, safe, stream);
         }
         case MBK_KERNEL_GROUP:
         case MBK_KERNEL_ASM:
@@ -592,7 +589,7 @@ int mbk_create(int device, mbk_ctx **out)
     ctx->device = device;
     static const uint32_t kDefaults[MBK_OPT_COUNT_] = {
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
-        /* SCAN_STEPS */ 16u, /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 2u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
+        /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
@@ -622,8 +619,8 @@ int mbk_create(int device, mbk_ctx **out)
         MBK_CREATE_HIP(hipHostMalloc((void **)&sl.h_red, sizeof(ReduceOut), hipHostMallocDefault));
     }
     {
-        const void *fns[2][2] = {{(const void *)mbk::tile_scan_kernel<double>, (const void *)mbk::tile_heavy_kernel<double>},
-                                 {(const void *)mbk::tile_scan_kernel<float>, (const void *)mbk::tile_heavy_kernel<float>}};
+        const void *fns[2][2] = {{(const void *)mbk::tile_light_kernel<double, true, true>, (const void *)mbk::tile_todo_kernel<double>},
+                                 {(const void *)mbk::tile_light_kernel<float, true, true>, (const void *)mbk::tile_todo_kernel<float>}};
         for (int f = 0; f < 2; ++f)
             for (int k = 0; k < 2; ++k) {
                 int n = 0;
@@ -940,9 +937,8 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_GROUP_STEPS: ok = value == 4u || value == 8u || value == 16u; break;
         case MBK_OPT_EXACT_STEPS: ok = value <= 4096u; break;
         case MBK_OPT_PROBE_STEPS: ok = value >= 2u && value <= 65536u; break;
-        case MBK_OPT_SCAN_STEPS: ok = value % 16u == 0u && value <= 65536u; break;
         case MBK_OPT_SCAN_WAVES: ok = value >= 1u && value <= 8u; break;
-        case MBK_OPT_SCAN_XCD_MAP: ok = value <= 2u; break;
+        case MBK_OPT_SCAN_XCD_MAP: ok = value <= 1u; break;
         case MBK_OPT_SCAN_COL_PERIOD: ok = value <= 65536u; break;
         case MBK_OPT_HEAVY_SHARE: ok = value <= 65536u; break;
         case MBK_OPT_RF_LIVEMIN: ok = value <= 63u; break;

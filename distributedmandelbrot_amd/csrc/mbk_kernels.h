@@ -159,32 +159,27 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
 // double (the reference's arithmetic) and float (cfg4's fp32 variant) as overloads.
 #define MBK_T double
 #define MBK_F "f64"
+#define MBK_CI_FROM_T64 "v_add_f64 %[ci], %[t64], %[start]\n"
 #include "mbk_loops.inc"
 #undef MBK_T
 #undef MBK_F
+#undef MBK_CI_FROM_T64
 #define MBK_T float
 #define MBK_F "f32"
+#define MBK_CI_FROM_T64 "v_add_f64 %[t64], %[t64], %[start]\nv_cvt_f32_f64 %[ci], %[t64]\n"
 #include "mbk_loops.inc"
 #undef MBK_T
 #undef MBK_F
+#undef MBK_CI_FROM_T64
 
 
-// T = double: the reference's arithmetic.  T = float: the fp32 variant (coordinates are generated in
-// fp64 exactly as for the fp64 path and then rounded once to fp32; the loop is strict fp32).
-template <typename T, bool kFmaDouble, int kGroup = 0>
-__global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
+// One pixel of an 8x8 block, start to finish (one lane each; the whole wave calls it): coordinates, the
+// escape loop of the chosen kind, the stores.  T = double: the reference's arithmetic.  T = float: the fp32
+// variant (coordinates are generated in fp64 exactly as for the fp64 path and then rounded once to fp32; the
+// loop is strict fp32).  long_groups (wave-uniform, kGroup == 16 only): 16-step groups for this block.
+template <typename T, bool kFmaDouble, int kGroup>
+__device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint32_t lr, bool long_groups)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    // Dispatch order != image order when an order list is given (heavy-first, classify_blocks_kernel)
-    // or perm_mul != 1 (multiplicative permutation, coprime to the grid size).
-    const uint32_t blk = p.order ? p.order[blockIdx.x]
-                                 : (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
-    if (p.order && p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)   // cursors sit behind the list
-        *p.heavy_hint = (uint32_t)(((uint64_t)p.order[gridDim.x] << 16) / gridDim.x);
-    const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
-    const uint32_t lc = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);  // one 8x8 block per wave
-    const uint32_t lr = by * 8u + (lane >> 3);
     if (lc >= p.ncols || lr >= p.nrows) return;
     const T cr = (T)axis_value(p.re, p.col0 + lc);
     const T ci = (T)axis_value(p.im, p.row0 + lr);
@@ -199,9 +194,8 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
         if (risky) {
             count = escape_count_asm<true>(cr, ci, p.mrd, &m);
         } else if (kGroup == 16) {
-            // 16-step groups (6.125 issue slots per step) only where the test hardly ever trips: the blocks the
-            // heavy-first probe put at the front of the dispatch order (interior of the set); 8 elsewhere
-            const bool long_groups = !p.order || blockIdx.x < p.order[gridDim.x];   // wave-uniform
+            // 16-step groups (6.125 issue slots per step) only where the test hardly ever trips (interior of
+            // the set: the blocks a probe or the light pass classified as such); 8 elsewhere
             count = long_groups ? escape_count_group<16>(cr, ci, p.mrd, &m, p.exact_steps)
                                 : escape_count_group<8>(cr, ci, p.mrd, &m, p.exact_steps);
         } else {
@@ -214,6 +208,26 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     if (p.counts) p.counts[o] = count;
     if (p.bytes) p.bytes[o] = quantise(count, p);
     if (p.smooth) p.smooth[o] = smooth_value(count, (double)m);
+}
+
+// Kernels "asm" (kGroup = 0) and "group": one 8x8 block per wave, blockDim / 64 blocks per workgroup.
+template <typename T, bool kFmaDouble, int kGroup = 0>
+__global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    // Dispatch order != image order when an order list is given (heavy-first, classify_blocks_kernel)
+    // or perm_mul != 1 (multiplicative permutation, coprime to the grid size).
+    const uint32_t blk = p.order ? p.order[blockIdx.x]
+                                 : (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
+    if (p.order && p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)   // cursors sit behind the list
+        *p.heavy_hint = (uint32_t)(((uint64_t)p.order[gridDim.x] << 16) / gridDim.x);
+    const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
+    const uint32_t lc = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);  // one 8x8 block per wave
+    const uint32_t lr = by * 8u + (lane >> 3);
+    // the blocks the heavy-first probe put at the front of the dispatch order take the 16-step groups
+    const bool long_groups = kGroup == 16 && (!p.order || blockIdx.x < p.order[gridDim.x]);   // wave-uniform
+    block_pixel<T, kFmaDouble, kGroup>(p, lc, lr, long_groups);
 }
 
 // ---------------------------------------------------------------------------------------------

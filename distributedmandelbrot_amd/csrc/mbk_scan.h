@@ -1,49 +1,62 @@
-// mbk_scan.h -- kernel "scan" (default since round 2): a persistent pass over all 8x8 blocks of a tile, then
-// one workgroup per block that is still running.
+// mbk_scan.h -- kernel "scan" (round 2): a persistent LIGHT pass over all 8x8 blocks of a tile, then one
+// workgroup per block the light pass could not finish.
 //
 // Why: with one single-wave workgroup per 8x8 block (kernels "asm"/"group") a 4096^2 tile is 262 144
-// workgroups, and the workgroup dispatcher -- not the VALU, not HBM -- bounds every block whose pixels
-// escape within a few steps (0.27 ns per workgroup: the all-exterior DataChunk (4,0,0) took 71 us against
-// an HBM-write floor of ~15 us, and at level 16 of the reference's pyramid 3 tiles in 4 are of that kind).
-// The light blocks need coarse, static scheduling (they all cost the same); the heavy ones -- whose cost
-// varies 100x -- need exactly what the hardware dispatcher is good at.  So:
+// workgroups, and every block whose pixels escape within a few steps is bound by the workgroup dispatcher
+// (0.27 ns each) and by its stores (below), not by arithmetic: the all-exterior DataChunk (4,0,0) took 71 us,
+// and at level 16 of the reference's pyramid 3 tiles in 4 are of that kind.  Light blocks need coarse,
+// static scheduling and the cheapest possible per-block code; heavy blocks -- whose cost varies 100x -- need
+// exactly what the hardware dispatcher is good at.  So:
 //
-//   pass 1  tile_scan_kernel   a grid that fills the chip once; wave w takes blocks w, w+W, w+2W, ...
-//           (W is a whole number of block rows whenever that fits: a wave stays in one block column for
-//           `col_period` sweeps -- the real coordinate is computed once per column -- and then jumps to a
-//           far column, so that no wave is stuck in the columns that cross the set).
-//           For each block: the first `scan_steps` steps of the reference loop (WorkerCUDA.py:39-68) --
-//           `exact_steps` with the per-step test, then whole grouped trips --, results written for
-//           every pixel (0 for the ones still running: that IS their final value if they never
-//           escape).  A block that still has running pixels is DEFERRED: its (zr, zi) state goes to
-//           HBM (16 B per pixel) and its id + live-lane mask are appended to one of 64 lists (block id
-//           mod 64; "dense" blocks -- every lane still running: interior of the set or of a slow
-//           region -- from the front of the list's slab, the others from its back).
-//   pass 2  tile_heavy_kernel  one single-wave workgroup per deferred block, dealt by the hardware
-//           dispatcher: workgroup j takes element j div 64 of list j mod 64 (dense elements first, so
-//           the long blocks start first), reloads the state and continues the grouped loop at step
-//           `scan_steps`; lanes that escape overwrite their 0.  The host cannot know how many blocks
-//           pass 1 deferred without a round trip, so the grid is 64 x (a hint): the longest list of the
-//           PREVIOUS launch on the stream, which pass 2 itself writes to pinned host memory, plus
-//           25 %; workgroups beyond a list's end leave after one load, and if the hint was too small a
-//           workgroup simply continues with element j div 64 + hint, + 2 hint, ... of its list.
-//           (Two persistent designs were measured first on cfg2, 510 us of work in this pass: popping
-//           with one atomicAdd per block took 770 us -- the waves of a SIMD finish equal blocks in
-//           lock-step, 128 of them hit each cursor at once, 29 us per pop; a static deal took 563 us
-//           but lost 35 % on the deep zoom cfg3, whose blocks all look alike after 24 steps and then
-//           run for 25 ... 9999.)
+//   pass 1  tile_light_kernel   a grid that fills the chip once; wave w takes blocks w, w+W, w+2W, ...  W is
+//           a whole number of block rows, so a wave stays in one block column (real coordinate and its
+//           square computed once) for `col_period` sweeps, then jumps to a far column (otherwise the waves
+//           whose column crosses the set would carry all the unfinished blocks).  Per interior block ONE asm
+//           sequence (mbk_loops.inc: escape_light_block): imaginary coordinate, |c| = 2 ring check, four
+//           branch-free steps of the reference loop (WorkerCUDA.py:39-68), and -- if every lane escaped --
+//           the stores, addressed as uniform base + constant lane offset.  ~30 VALU and ~20 scalar
+//           instructions per block.  A block that is not finished (a lane still inside after 4 steps, a
+//           pixel near the ring, a ragged edge, the axis' pinned end point) is put on a TODO list, nothing
+//           else: its id goes into a lane of a staging register (v_writelane, no memory traffic), and the
+//           wave appends its staged ids to one of 64 lists with one atomicAdd per 64 ids ("dense" blocks --
+//           all 64 lanes still inside: interior of the set or of a slow region -- to the front of the
+//           list's slab, the others to its back).
+//   pass 2  tile_todo_kernel    one single-wave workgroup per listed block, dealt by the hardware dispatcher
+//           (workgroup j: element j div 64 of list j mod 64, dense elements first: longest jobs first),
+//           which computes the block from scratch exactly like kernel "group" (block_pixel: per-step
+//           prologue, grouped loops with exact replay, 16-step groups for dense blocks).  The 4 steps pass
+//           1 spent on it are redone: 36 of the >6000 instructions of an interior block.
+//           The host cannot know how many blocks are listed without a round trip, so the grid is 64 x (a
+//           hint): the longest list of the PREVIOUS launch on the stream, which this pass writes to
+//           pinned host memory, + 25 %, never less than the chip holds; workgroups past a list's end leave
+//           after one load, and if the hint was too small a workgroup strides on through its list.
 //
-// Bit-exactness: every pixel runs exactly the arithmetic of the "group" kernel (same loops from
-// mbk_loops.inc, same state, only split at a step boundary and moved through HBM as raw bits); waves
-// touching the |c| = 2 ring finish in pass 1 with the per-step loop.  Nothing in the results depends on
-// which wave processes which block, nor on the hint.
+// XCD-aware order: the hardware deals consecutive workgroup ids to the 8 XCDs in turn, each with its own L2.
+// In image order the four 8-pixel-wide blocks sharing a 128-byte line of the output are written by four
+// XCDs: profiles/microbench/light_path.hip measures 25.6 us for the bare 8x8 store pattern of a 4096^2 int32
+// tile, against 12.9 us when a bit permutation of the wave -> column map gives each XCD runs of four adjacent
+// block columns (and 11.9 us for the arithmetic of the light path).  Lists are indexed by wave id mod 64, so
+// pass 2 continues a block on the XCD that listed it.
 //
-// Scratch (per stream, mbk_api.hip): entries 16 B per block, state 2*sizeof(T) B per pixel (worst case:
-// every block deferred), two cursor sets used alternately -- pass 1 of launch L clears the set of launch
-// L+1, so no memset sits between launches (launches on one stream are ordered) -- and the 4-byte hint.
+// History (all measured on cfg2, 510 us of interior work): a persistent pass 2 popping blocks with one
+// atomicAdd each took 770 us (the waves of a SIMD finish equal blocks in lock-step, 128 of them hit each
+// cursor at once, 29 us per pop); a static deal 563 us but -35 % on the deep zoom cfg3; a pass 1 that ran the
+// first 24 steps and handed pass 2 the (zr, zi) state through HBM was no faster than redoing 4 steps and
+// needed 16 B of scratch per pixel.  Two traps are recorded where they bit: gridDim.x is re-read from the
+// dispatch packet in HOST memory on every trip of a persistent loop unless passed as an argument (pass 1 took
+// 110 us instead of 37), and hipMemset on the null stream does not order against a non-blocking stream.
+//
+// Bit-exactness: a block finished by pass 1 went through the branch-free prologue, which is exact because
+// |z|^2 >= 4 stays >= 4 (the property the grouped test relies on; waves with a pixel near |c| = 2 never use
+// it); every other block is computed by the same code as kernel "group".  Nothing depends on the lists'
+// order or on the hint.
+//
+// Scratch (per stream, mbk_api.hip): 4 B per block of list space, two cursor sets used alternately -- pass 1 of
+// launch L clears the set of launch L+1, so no memset sits between launches (launches on one stream are
+// ordered) -- and 8 B of pinned host memory for the hints.
 #pragma once
 
-#include "mbk_refill.h"  // lane_in, uniform_u32/u64 (includes mbk_kernels.h)
+#include "mbk_refill.h"  // uniform_u32/u64 (includes mbk_kernels.h)
 
 namespace mbk {
 
@@ -55,178 +68,140 @@ struct ScanCursors {  // one 64-byte line per list: lengths, appended to by pass
     } q[kScanQueues];
 };
 
-struct ScanEntry {
-    uint32_t block;
-    uint32_t pad;
-    unsigned long long live;  // lanes still running after pass 1
-};
-
 struct ScanArgs {
     ScanCursors *cur;       // this launch's cursors (all zero on entry)
     ScanCursors *cur_next;  // cleared by pass 1 for the next launch on this stream
-    ScanEntry *entries;     // kScanQueues * qcap
-    void *state;            // kScanQueues * qcap * 64 * {T zr, T zi}
+    uint32_t *entries;      // kScanQueues * qcap block ids
     uint32_t *hint_out;     // pinned host memory, 2 words written by pass 2: the longest list's length (next
-                            // launch's grid hint) and the deferred share of all blocks x 65536 (kernel choice)
-    uint32_t qcap;          // entries per list = ceil(nblocks / 64)
+                            // launch's grid hint) and the listed share of all blocks x 65536 (kernel choice)
+    uint32_t qcap;          // entries per list (>= the most blocks the waves of one list can hold)
     uint32_t nblocks;
-    uint32_t scan_steps;    // pass 1 depth: exact_steps + a multiple of 16
     // Grid sizes as explicit arguments: gridDim.x lives in the dispatch packet, and the compiler re-read
-    // it on every trip of the block loop -- a host-memory access per block, ~3 us each: pass 1 of an
-    // all-exterior tile took 110 us instead of 37.
-    uint32_t stride;        // pass 1: wave w takes blocks w, w + stride, ...
-    uint32_t stride_bx;     // stride mod blocks_x (0: whole block rows per sweep)
-    uint32_t stride_by;     // stride div blocks_x
-    uint32_t col_period;    // pass 1, stride_bx == 0: sweeps a wave stays in one block column (0 = for ever)
+    // it on every trip of the block loop -- a host-memory access per block, ~3 us each.
+    uint32_t stride_by;     // pass 1: block rows per sweep (the grid is stride_by whole block rows)
+    uint32_t col_period;    // pass 1: sweeps a wave stays in one block column (0 = for ever)
     uint32_t col_jump;      // ... then it moves this many block columns to the right (mod blocks_x)
-    uint32_t xcd_map;       // pass 1: 1 = XCD-aware block-column permutation (needs blocks_x % 32 == 0, stride_bx == 0)
+    uint32_t xcd_map;       // pass 1: 1 = XCD-aware block-column permutation (needs blocks_x % 32 == 0)
+    uint32_t fast_by_end;   // pass 1: block rows below this one are whole and hold no pinned end point
+    uint32_t fast_bx_end;   // pass 1: block columns below this one are whole
+    uint32_t qtab;          // pass 1: quantised bytes of counts 1..4, packed (byte k-1 = quantise(k))
     uint32_t ranks2;        // pass 2: elements per list covered by the grid (grid = 64 * ranks2)
     uint32_t long_groups;   // pass 2: 1 = dense blocks use 16-step groups (option group_steps == 16)
 };
 
-template <typename T>
-struct ScanState {
-    T zr, zi;
-};
-
-// np.linspace sample k for the views this kernel accepts (step != 0; the host sends the others to the
-// "group" kernel): fl(fl(k*step) + start), end point pinned.  Same arithmetic as axis_value.
-__device__ __forceinline__ double scan_axis_value(const Axis &a, uint32_t k)
+// staged[lane n] = id (id, n wave-uniform): one v_writelane, no memory traffic
+__device__ __forceinline__ void scan_stage(uint32_t &staged, uint32_t id, uint32_t n)
 {
-    const double v = (double)k * a.step + a.start;
-    return (k + 1u == a.n) ? a.last : v;
+    const uint32_t id_s = uniform_u32(id), n_s = uniform_u32(n);
+    // (the lane select goes through M0: two SGPR operands would exceed gfx9's constant-bus limit)
+    uint32_t saved_m0;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(staged), "=&s"(saved_m0)
+                 : "s"(id_s), "s"(n_s));
 }
 
-template <typename T>
-__device__ __forceinline__ void store_results(const TileArgs &p, size_t o, int32_t count, T m)
+// Append the `n` block ids staged in lanes 0..n-1 of `staged` to list q: one atomicAdd for the whole batch.
+__device__ __forceinline__ void scan_flush(const ScanArgs &s, uint32_t q, uint32_t staged, uint32_t n, bool dense,
+                                           uint32_t lane)
 {
-    if (p.counts) p.counts[o] = count;
-    if (p.bytes) p.bytes[o] = quantise(count, p);
-    if (p.smooth) p.smooth[o] = smooth_value(count, (double)m);
+    uint32_t idx0 = 0;
+    if (lane == 0) idx0 = atomicAdd(dense ? &s.cur->q[q].tail_dense : &s.cur->q[q].tail_sparse, n);
+    idx0 = uniform_u32(idx0);
+    if (lane < n) s.entries[q * s.qcap + (dense ? idx0 + lane : s.qcap - 1u - (idx0 + lane))] = staged;
 }
 
-template <typename T>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(94))) void tile_scan_kernel(TileArgs p, ScanArgs s)
+// kCounts / kBytes: which outputs the light path stores (the host picks the instantiation that matches the
+// pointers in TileArgs).  Launches that the light path cannot serve at all (smooth output, 64-bit quantiser,
+// fewer than 4 steps, windows narrower than the chip) do not come here: the host sends them to "group".
+template <typename T, bool kCounts, bool kBytes>
+__global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
 {
     const uint32_t lane = threadIdx.x;
     if (blockIdx.x == 0) {  // clear the next launch's cursors
         unsigned int *w = reinterpret_cast<unsigned int *>(s.cur_next);
         for (uint32_t k = lane; k < (uint32_t)(sizeof(ScanCursors) / 4u); k += 64u) w[k] = 0u;
     }
-    const uint32_t total = p.mrd > 1 ? (uint32_t)p.mrd - 1u : 0u;
-    const uint32_t first = total < p.exact_steps ? total : p.exact_steps;
-    const uint32_t depth = total < s.scan_steps ? total : s.scan_steps;
-    const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
-    ScanState<T> *state = static_cast<ScanState<T> *>(s.state);
-    const bool use_prologue = p.smooth == nullptr && depth >= 4u;   // (depth >= 4: pass 1 runs at least 4 steps)
-
-    // Block coordinates are kept incrementally: one sweep is (bx, by) -> (bx + stride_bx, by + stride_by).
-    // XCD-aware start (s.xcd_map): the hardware deals consecutive workgroup ids to the 8 XCDs in turn, each
-    // with its own L2.  With the identity mapping the four 8-pixel-wide blocks that share a 128-byte line of
-    // the output are written by four different XCDs and reach HBM as four partial lines; the bit
-    // permutation below gives each XCD runs of four adjacent block columns, so a line is completed in ONE L2.
-    // (col_jump is a multiple of 32 columns, which keeps that property.)
+    const uint32_t q = blockIdx.x & (kScanQueues - 1u);   // this wave's list
     uint32_t by = blockIdx.x / p.blocks_x, bx = blockIdx.x - by * p.blocks_x;
     if (s.xcd_map) {
         const uint32_t a = bx >> 3, c = bx & 7u;         // bx = 8a + c, c = the XCD this wave runs on
         bx = ((a >> 2) << 5) | (c << 2) | (a & 3u);
     }
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    uint32_t lc = bx * 8u + lx;
-    T cr = (T)scan_axis_value(p.re, p.col0 + lc);
+    const uint32_t lane_elem = ly * p.out_pitch + lx;    // constant per-lane offset of the stores
+    T cr = (T)axis_value(p.re, p.col0 + bx * 8u + lx);
+    T a0 = cr * cr;
     uint32_t sweeps_here = 0;
+    uint32_t staged_d = 0, staged_s = 0, nd = 0, ns = 0;  // staged ids (lane k = k-th id) and their numbers
     const uint32_t nby = (p.nrows + 7u) / 8u;
-    for (; by < nby; by += s.stride_by) {
-        // (stride_bx != 0 -- a grid that is not a whole number of block rows -- only happens for windows
-        // narrower than the chip or wider than 65536 pixels; then by may step past the last row by one)
-        const uint32_t b = by * p.blocks_x + bx;
-        if (b >= s.nblocks) break;
-        const uint32_t lr = by * 8u + ly;
-        const bool valid = lc < p.ncols && lr < p.nrows;
-        bool running = false;
-        T zr = 0, zi = 0;
-        if (valid) {
-            const T ci = (T)scan_axis_value(p.im, p.row0 + lr);
-            T a, bq, m = 0;
-            int32_t cnt = 0;
-            zr = cr;
-            zi = ci;
-            a = zr * zr;
-            bq = zi * zi;
-            // waves touching the |c| = 2 ring: per-step loop to the end (see tile_asm_kernel)
-            bool risky = false;
-            if (p.ring_possible) {
-                const T c2 = a + bq;
-                risky = __any(c2 > (T)4 - margin && c2 < (T)4 + margin) != 0;
+    while (by < nby) {
+        uint32_t todo = 0u;   // 0 finished, 1 some lane still inside, 2 not attempted / near the ring
+        bool dense = false;
+        if (bx < s.fast_bx_end && by < s.fast_by_end) {
+            // tight loop over this wave's consecutive light blocks: the bases advance by a constant
+            const size_t elem0 = (size_t)(by * 8u + p.out_row0) * p.out_pitch + bx * 8u + p.out_col0;
+            int32_t *cptr = kCounts ? p.counts + elem0 : nullptr;
+            uint8_t *bptr = kBytes ? p.bytes + elem0 : nullptr;
+            const size_t einc = (size_t)s.stride_by * 8u * p.out_pitch;
+            T ci, zr, zi, a, bq;
+            int32_t cnt;
+            for (;;) {
+                const uint32_t row = p.row0 + by * 8u + ly;
+                // (the bases are wave-uniform; saying so explicitly keeps them in SGPRs, which the asm needs)
+                int32_t *cb = reinterpret_cast<int32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(cptr)));
+                uint8_t *bb = reinterpret_cast<uint8_t *>(uniform_u64(reinterpret_cast<unsigned long long>(bptr)));
+                todo = p.ring_possible   // wave-uniform
+                           ? escape_light_block<kCounts, kBytes, true>(cr, a0, row, p.im.step, p.im.start, ci, zr, zi, a, bq, cnt,
+                                                                       cb, lane_elem * 4u, bb, lane_elem, s.qtab)
+                           : escape_light_block<kCounts, kBytes, false>(cr, a0, row, p.im.step, p.im.start, ci, zr, zi, a, bq, cnt,
+                                                                        cb, lane_elem * 4u, bb, lane_elem, s.qtab);
+                if (todo != 0u) break;
+                const uint32_t by_next = by + s.stride_by;
+                if ((s.col_period != 0u && sweeps_here + 1u == s.col_period) || by_next >= s.fast_by_end) break;
+                by = by_next;
+                ++sweeps_here;
+                if (kCounts) cptr += einc;
+                if (kBytes) bptr += einc;
             }
-            if (risky) {
-                escape_steps_asm<true>(cr, ci, zr, zi, a, bq, m, cnt, 0u, total);
-            } else {
-                uint32_t done = 0u;   // steps already taken by the lanes still running
-                bool inside = true;
-                if (use_prologue) {   // wave-uniform: 4 branch-free steps, see escape_steps_prologue4
-                    escape_steps_prologue4(cr, ci, zr, zi, a, bq, cnt);
-                    inside = cnt == 5;
-                    cnt = inside ? 0 : cnt;
-                    done = 4u;
-                }
-                if (inside) {
-                    if (first > done) escape_steps_asm<true>(cr, ci, zr, zi, a, bq, m, cnt, done, first);
-                    const uint32_t from = first > done ? first : done;
-                    if (cnt == 0 && depth > from) escape_steps_group<8>(cr, ci, zr, zi, a, bq, m, cnt, from, depth);
-                    running = cnt == 0 && total > depth;
-                }
-            }
-            store_results<T>(p, (size_t)(lr + p.out_row0) * p.out_pitch + lc + p.out_col0, cnt, m);
+            dense = todo == 1u && __ballot(cnt == 5) == ~0ull;
+        } else {
+            todo = 2u;
         }
-        const unsigned long long live = __ballot(running);
-        if (live != 0ull) {  // wave-uniform: defer the block
-            const uint32_t q = b & (kScanQueues - 1u);
-            const bool dense = live == ~0ull;
-            uint32_t idx = 0;
-            if (lane == 0) idx = atomicAdd(dense ? &s.cur->q[q].tail_dense : &s.cur->q[q].tail_sparse, 1u);
-            idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
-            const uint32_t e = q * s.qcap + (dense ? idx : s.qcap - 1u - idx);
-            if (lane == 0) {
-                s.entries[e].block = b;
-                s.entries[e].live = live;
-            }
-            if (running) {
-                ScanState<T> st;
-                st.zr = zr;
-                st.zi = zi;
-                state[(size_t)e * 64u + lane] = st;
+        if (todo != 0u) {   // wave-uniform: stage the block id; flush a full register
+            const uint32_t b = by * p.blocks_x + bx;
+            if (dense) {
+                scan_stage(staged_d, b, nd);
+                if (++nd == 64u) {
+                    scan_flush(s, q, staged_d, nd, true, lane);
+                    nd = 0u;
+                }
+            } else {
+                scan_stage(staged_s, b, ns);
+                if (++ns == 64u) {
+                    scan_flush(s, q, staged_s, ns, false, lane);
+                    ns = 0u;
+                }
             }
         }
         // next block of this wave: same column, stride_by rows down -- except every col_period sweeps
-        // (or on every sweep when the grid is not a whole number of rows)
-        bool moved = false;
-        if (s.stride_bx != 0u) {
-            bx += s.stride_bx;
-            if (bx >= p.blocks_x) {
-                bx -= p.blocks_x;
-                by += 1u;
-            }
-            moved = true;
-        } else if (s.col_period != 0u && ++sweeps_here == s.col_period) {
+        by += s.stride_by;
+        if (s.col_period != 0u && ++sweeps_here >= s.col_period) {
             sweeps_here = 0u;
             bx += s.col_jump;
             if (bx >= p.blocks_x) bx -= p.blocks_x;
-            moved = true;
-        }
-        if (moved) {  // wave-uniform
-            lc = bx * 8u + lx;
-            cr = (T)scan_axis_value(p.re, p.col0 + lc);
+            cr = (T)axis_value(p.re, p.col0 + bx * 8u + lx);
+            a0 = cr * cr;
         }
     }
+    if (nd != 0u) scan_flush(s, q, staged_d, nd, true, lane);
+    if (ns != 0u) scan_flush(s, q, staged_s, ns, false, lane);
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void tile_heavy_kernel(TileArgs p, ScanArgs s)
+__global__ __launch_bounds__(64) void tile_todo_kernel(TileArgs p, ScanArgs s)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t q = blockIdx.x & (kScanQueues - 1u);
-    uint32_t i = blockIdx.x >> 6;
     const uint32_t len_d = s.cur->q[q].tail_dense, len = len_d + s.cur->q[q].tail_sparse;
     if (blockIdx.x == 0) {  // next launch's hints (posted writes to pinned host memory)
         uint32_t n = s.cur->q[lane].tail_dense + s.cur->q[lane].tail_sparse, sum = n;
@@ -240,26 +215,12 @@ __global__ __launch_bounds__(64) void tile_heavy_kernel(TileArgs p, ScanArgs s)
             s.hint_out[1] = (uint32_t)(((uint64_t)sum << 16) / s.nblocks);
         }
     }
-    const uint32_t total = p.mrd > 1 ? (uint32_t)p.mrd - 1u : 0u;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const ScanState<T> *state = static_cast<const ScanState<T> *>(s.state);
-    for (; i < len; i += s.ranks2) {  // one trip when the hint was large enough
-        const uint32_t e = q * s.qcap + (i < len_d ? i : s.qcap - 1u - (i - len_d));
-        const uint32_t blk = uniform_u32(s.entries[e].block);
-        const unsigned long long live = uniform_u64(s.entries[e].live);
+    for (uint32_t i = blockIdx.x >> 6; i < len; i += s.ranks2) {  // one trip when the hint was large enough
+        const uint32_t blk = uniform_u32(s.entries[q * s.qcap + (i < len_d ? i : s.qcap - 1u - (i - len_d))]);
         const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
-        const uint32_t lc = bx * 8u + lx, lr = by * 8u + ly;
-        if (lane_in(live)) {
-            const ScanState<T> st = state[(size_t)e * 64u + lane];
-            const T cr = (T)scan_axis_value(p.re, p.col0 + lc);
-            const T ci = (T)scan_axis_value(p.im, p.row0 + lr);
-            T zr = st.zr, zi = st.zi, a = zr * zr, bq = zi * zi, m = 0;
-            int32_t cnt = 0;
-            // dense blocks (interior): 16-step groups, 6.125 slots per step; the others: 8 (cheaper replays)
-            if (s.long_groups && i < len_d) escape_steps_tail<16>(cr, ci, zr, zi, a, bq, m, cnt, s.scan_steps, total);
-            else escape_steps_group<8>(cr, ci, zr, zi, a, bq, m, cnt, s.scan_steps, total);
-            if (cnt > 0) store_results<T>(p, (size_t)(lr + p.out_row0) * p.out_pitch + lc + p.out_col0, cnt, m);
-        }
+        // dense blocks (interior): 16-step groups, 6.125 slots per step; the others: 8 (cheaper replays)
+        block_pixel<T, true, 16>(p, bx * 8u + lx, by * 8u + ly, s.long_groups != 0u && i < len_d);
     }
 }
 

@@ -53,8 +53,8 @@ enum mbk_status {
 #define MBK_KERNEL_ASM 0x200u    /* one lane per pixel, hand-scheduled gfx950 loop */
 #define MBK_KERNEL_REFILL 0x300u /* persistent waves with lane refill (deep-zoom divergence) */
 #define MBK_KERNEL_GROUP 0x400u  /* hand-scheduled loop, bailout tested once per 16 (interior) / 8 steps + exact replay; one workgroup per 8x8 block */
-#define MBK_KERNEL_SCAN 0x500u   /* the same loops in two persistent passes: a chip-filling scan that finishes every block
-                                    whose pixels escape early, then a work-queue pass over the deferred blocks */
+#define MBK_KERNEL_SCAN 0x500u   /* a persistent light pass that finishes every block whose pixels escape within 4 steps,
+                                    then one workgroup (the "group" code) per block it listed as unfinished */
 
 /* Arithmetic of the escape loop (bit 12).  Default = IEEE binary64, the reference's arithmetic.
  * MBK_PRECISION_F32 is BASELINE config 4's "fp32 kernel variant" -- NOT in the reference (its only
@@ -137,7 +137,7 @@ int mbk_datachunk_geometry(uint32_t level, uint32_t index_real, uint32_t index_i
  * MBK_WANT_COUNTS); d_bytes: uint8[nrows*ncols] (or NULL without MBK_WANT_BYTES).
  * mrd is the reference's "maximum recursion depth": at most mrd-1 updates, result in {0} U [1, mrd-1].
  * A launch may enqueue helper kernels (scan pass, dispatch-order pre-pass, work-queue reset) that use
- * scratch memory the ctx keeps PER STREAM (up to 18 B per pixel of the largest window seen on that
+ * scratch memory the ctx keeps PER STREAM (a few bytes per 8x8 block of the largest window seen on that
  * stream): launches on one stream are ordered, so any number may be queued, on any number of streams.
  */
 int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
@@ -211,12 +211,10 @@ enum mbk_option {
     MBK_OPT_WAVES_PER_WG,  /* asm/group: 8x8 blocks per workgroup: [1], 2, 4 */
     MBK_OPT_GROUP_STEPS,   /* group / scan pass 2: steps per grouped bailout test: 4, 8, [16] (16 applies to the blocks
                               classified as interior -- probe-heavy / dense --, the rest keep 8) */
-    MBK_OPT_EXACT_STEPS,   /* scan/group: steps tested one by one before the grouped test takes over: 0..4096 [8] */
+    MBK_OPT_EXACT_STEPS,   /* group / scan pass 2: steps tested one by one before the grouped test takes over: 0..4096 [8] */
     MBK_OPT_PROBE_STEPS,   /* asm/group: depth of the heavy-first probe: 2..65536 [32] */
-    MBK_OPT_SCAN_STEPS,    /* scan: grouped steps pass 1 runs after the exact ones, a multiple of 16: 0..65536 [16] */
     MBK_OPT_SCAN_WAVES,    /* scan: resident waves per SIMD of pass 1: 1..[8] */
-    MBK_OPT_SCAN_XCD_MAP,  /* scan: XCD-aware block-column order in pass 1 (a 128-byte output line is completed in one L2):
-                              0 off, 1 on, [2] on when the quantised bytes are written */
+    MBK_OPT_SCAN_XCD_MAP,  /* scan: XCD-aware block-column order (a 128-byte output line is completed in one L2): 0, [1] */
     MBK_OPT_SCAN_COL_PERIOD, /* scan: sweeps a pass-1 wave stays in one block column before jumping to a far one: 0 (never) .. 65536 [4] */
     MBK_OPT_HEAVY_SHARE,   /* default kernel: share of heavy blocks (x 65536) in the previous launch on the stream above
                               which the next one uses "group" instead of "scan": 0..65536 [655 = 1 %] */

@@ -389,8 +389,8 @@ def test_smooth_buffer_survives_serialize_last(gpu, oracle):
 
 
 OPTION_MATRIX = [
-    ("scan", {"exact_steps": 0}), ("scan", {"exact_steps": 3}), ("scan", {"scan_steps": 0}),
-    ("scan", {"scan_steps": 48}), ("scan", {"scan_waves": 1}), ("scan", {"scan_xcd_map": 0}), ("scan", {"scan_xcd_map": 1}),
+    ("scan", {"exact_steps": 0}), ("scan", {"exact_steps": 3}),
+    ("scan", {"exact_steps": 64}), ("scan", {"scan_waves": 1}), ("scan", {"scan_xcd_map": 0}), ("scan", {"scan_xcd_map": 1}),
     ("scan", {"scan_col_period": 0}), ("scan", {"scan_col_period": 1, "scan_xcd_map": 0}), ("scan", {"scan_waves": 3, "exact_steps": 16}),
     ("group", {"exact_steps": 0}), ("group", {"exact_steps": 5}), ("group", {"group_steps": 4}), ("group", {"group_steps": 8}), ("group", {"group_steps": 16, "order": 0}),
     ("scan", {"group_steps": 8}),
@@ -421,7 +421,7 @@ def test_option_matrix_is_bit_exact(oracle, kernel, options):
         with pytest.raises(MbkError):
             dev.set_option("group_steps", 5)
         with pytest.raises(MbkError):
-            dev.set_option("scan_steps", 17)
+            dev.set_option("scan_waves", 9)
         for view, mrd in cases:
             _check_view(dev, oracle, view, mrd, kernel=kernel)
 
