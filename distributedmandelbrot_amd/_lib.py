@@ -30,6 +30,7 @@ OPTIONS = {name: i for i, name in enumerate(
     ["order", "waves_per_wg", "group_steps", "exact_steps", "probe_steps", "scan_waves", "scan_xcd_map", "scan_col_period", "heavy_share",
      "rf_livemin", "rf_patience", "rf_batch", "rf_waves"])}
 MBK_PRECISION_F32 = 0x1000
+MBK_LAZY_UNIFORM = 0x2000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
 MBK_SLOTS = 2
 MBK_CODEC_RAW = 0x00
@@ -85,6 +86,8 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.POINTER(mbk_stats)]),
     "mbk_datachunk_submit": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.c_void_p, C.c_void_p]),
+    "mbk_datachunk_submit_ex": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_uint32]),
     "mbk_view_submit": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(mbk_view), C.c_uint32, C.c_uint32,
                                   C.c_void_p, C.c_void_p]),
     "mbk_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(mbk_stats)]),

@@ -57,6 +57,8 @@ struct Slot {
     ReduceOut *h_red = nullptr;  // pinned
     bool busy = false;           // submitted, not yet waited for
     bool with_bytes = false;
+    uint8_t *lazy_h_bytes = nullptr;  // MBK_LAZY_UNIFORM: the byte copy is decided in mbk_wait
+    size_t lazy_px = 0;
 };
 
 struct mbk_ctx {
@@ -229,8 +231,9 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     const uint32_t order_mode = ctx->opt[MBK_OPT_ORDER], probe_steps = ctx->opt[MBK_OPT_PROBE_STEPS];
     a.perm_mul = order_mode == 1 ? coprime_multiplier(grid.x) : 1u;
     a.order = nullptr;
-    if (order_mode == 2 && grid.x >= 4096u && (uint32_t)a.mrd > 2u * probe_steps) {
-        // heavy-first dispatch order (see classify_blocks_kernel); tiny launches skip it
+    if (order_mode == 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps) {
+        // heavy-first dispatch order (see classify_blocks_kernel); small launches skip it: one kernel in image
+        // order beats memset + classify + tile below ~16 k blocks (cfg1, 4096 blocks: 20 us against 27)
         StreamScratch *sc = nullptr;
         int rc = get_scratch(ctx, stream, &sc);
         if (rc != MBK_OK) return rc;
@@ -485,10 +488,13 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
             // Default = whichever of the two was the better choice for the PREVIOUS launch on this stream
             // (both leave the share of heavy blocks in pinned memory; no host round trip, and a stale or
             // wrong hint only costs time).  With more than ~1 % of the blocks heavy the tile is bound by
-            // their arithmetic and the light blocks ride along for free in "group" (cfg2: scan 617 us,
-            // group 568); below that, "group" is bound by its 0.27 ns per workgroup and "scan" wins
-            // (all-exterior tile: 43 us against 71).  Small launches always take "scan".
-            if (kernel == MBK_KERNEL_DEFAULT && (uint64_t)((a.ncols + 7u) / 8u) * ((a.nrows + 7u) / 8u) >= 16384u) {
+            // their arithmetic and the light blocks ride along for free in "group" (cfg2: scan 597 us,
+            // group 568); below that, "group" is bound by its 0.27 ns per workgroup and its stores, and
+            // "scan" wins (all-exterior tile: 29 us against 71).  Launches under 16 k blocks take "group",
+            // which for them is a single kernel in image order (cfg1: 20 us, scan 24).
+            if (kernel == MBK_KERNEL_DEFAULT) {
+                if ((uint64_t)((a.ncols + 7u) / 8u) * ((a.nrows + 7u) / 8u) < 16384u)
+                    return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
                 StreamScratch *sc = nullptr;
                 rc = get_scratch(ctx, stream, &sc);
                 if (rc != MBK_OK) return rc;
@@ -737,9 +743,12 @@ static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mr
     rc = launch_reduce(ctx, sl, sl.d_counts, wb ? sl.d_bytes : nullptr, px, mrd, sl.stream);
     if (rc != MBK_OK) return rc;
     MBK_HIP(ctx, hipEventRecord(sl.ev_c0, sl.stream));
-    if (wb) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, sl.d_bytes, px, hipMemcpyDeviceToHost, sl.stream));
+    const bool lazy = wb && (flags & MBK_LAZY_UNIFORM) != 0;
+    if (wb && !lazy) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, sl.d_bytes, px, hipMemcpyDeviceToHost, sl.stream));
     if (wc) MBK_HIP(ctx, hipMemcpyAsync(h_counts, sl.d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost, sl.stream));
     MBK_HIP(ctx, hipEventRecord(sl.ev_c1, sl.stream));
+    sl.lazy_h_bytes = lazy ? h_bytes : nullptr;
+    sl.lazy_px = px;
     sl.busy = true;
     sl.with_bytes = wb;
     if (&sl == &ctx->s[0]) ctx->last_px = wb ? px : 0;
@@ -751,6 +760,16 @@ static int wait_slot(mbk_ctx *ctx, Slot &sl, mbk_stats *stats)
     if (!sl.busy) return fail(ctx, MBK_ERR_INVALID, "nothing was submitted on this slot");
     MBK_HIP(ctx, hipStreamSynchronize(sl.stream));
     sl.busy = false;
+    if (sl.lazy_h_bytes) {   // MBK_LAZY_UNIFORM: copy the bytes only if the tile is not all-0 / all-1
+        uint8_t *dst = sl.lazy_h_bytes;
+        sl.lazy_h_bytes = nullptr;
+        if (sl.h_red->any_byte_not_zero != 0 && sl.h_red->any_byte_not_one != 0) {
+            MBK_HIP(ctx, hipEventRecord(sl.ev_c0, sl.stream));
+            MBK_HIP(ctx, hipMemcpyAsync(dst, sl.d_bytes, sl.lazy_px, hipMemcpyDeviceToHost, sl.stream));
+            MBK_HIP(ctx, hipEventRecord(sl.ev_c1, sl.stream));
+            MBK_HIP(ctx, hipStreamSynchronize(sl.stream));
+        }
+    }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         MBK_HIP(ctx, hipEventElapsedTime(&stats->kernel_ms, sl.ev_k0, sl.ev_k1));
@@ -784,6 +803,12 @@ int mbk_view_compute(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t 
 int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
                          uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts)
 {
+    return mbk_datachunk_submit_ex(ctx, slot, level, mrd, index_real, index_imag, h_bytes, h_counts, 0u);
+}
+
+int mbk_datachunk_submit_ex(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
+                            uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, uint32_t flags)
+{
     if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
     if (slot < 0 || slot >= MBK_SLOTS) return fail(ctx, MBK_ERR_INVALID, "slot out of range");
     if (!h_bytes) return fail(ctx, MBK_ERR_INVALID, "h_bytes is NULL");
@@ -796,7 +821,9 @@ int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, u
     }
     mbk_view v;
     datachunk_view(&v, sr, si, range);
-    return submit_view(ctx, ctx->s[slot], &v, mrd, MBK_WANT_BYTES | (h_counts ? MBK_WANT_COUNTS : 0u), h_counts, h_bytes);
+    return submit_view(ctx, ctx->s[slot], &v, mrd,
+                       MBK_WANT_BYTES | (h_counts ? MBK_WANT_COUNTS : 0u) | (flags & (MBK_LAZY_UNIFORM | MBK_KERNEL_MASK)),
+                       h_counts, h_bytes);
 }
 
 int mbk_view_submit(mbk_ctx *ctx, int slot, const mbk_view *view, uint32_t mrd, uint32_t flags,

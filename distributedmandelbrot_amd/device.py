@@ -228,12 +228,15 @@ class MandelbrotDevice:
         return self._ser_buf[:size.value].tobytes(), int(codec.value)
 
     def submit_datachunk(self, slot: int, level: int, mrd: int, index_real: int, index_imag: int,
-                         out_bytes: np.ndarray) -> None:
+                         out_bytes: np.ndarray, lazy_uniform: bool = False) -> None:
         """Enqueue a tile on `slot` (0 or 1) and return at once; `out_bytes` (uint8[16777216], ideally from
-        pinned_empty) is valid after wait(slot).  Two slots = the D2H of one tile overlaps the next kernel."""
+        pinned_empty) is valid after wait(slot).  Two slots = the D2H of one tile overlaps the next kernel.
+        lazy_uniform: skip the 16 MiB copy when the tile turns out all-0 / all-1 -- `out_bytes` is then left
+        untouched and the TileStats returned by wait() say which constant it is (MBK_LAZY_UNIFORM)."""
         assert out_bytes.dtype == np.uint8 and out_bytes.size == L.MBK_CHUNK_BYTES and out_bytes.flags.c_contiguous
-        self._check(self._lib.mbk_datachunk_submit(self._h, slot, level, mrd, index_real, index_imag,
-                                                   out_bytes.ctypes.data, None))
+        self._check(self._lib.mbk_datachunk_submit_ex(self._h, slot, level, mrd, index_real, index_imag,
+                                                      out_bytes.ctypes.data, None,
+                                                      L.MBK_LAZY_UNIFORM if lazy_uniform else 0))
 
     def submit_view(self, slot: int, view: View, mrd: int, *, window=None, out_counts: Optional[np.ndarray] = None,
                     out_bytes: Optional[np.ndarray] = None, kernel: str = "default", precision: str = "f64") -> None:

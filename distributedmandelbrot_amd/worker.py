@@ -250,7 +250,7 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
                 return
             workload, buf, st = item
             try:
-                status, nsent = submit_workload_ex(addr, port, workload, buf)
+                status, nsent = submit_workload_ex(addr, port, workload, payload_of(buf, st))
                 log(f"{workload}: " + describe_stats(st))
                 _log_submit(status, nsent, log)
                 if status != SUBMIT_REJECTED:
@@ -260,6 +260,18 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
                 errors.append(e)
             finally:
                 free.put(buf)
+
+    # uniform tiles (3 in 4 of a pyramid level) are never copied off the GPU: the stats say which constant the
+    # tile is, and the 16 777 216 payload bytes the protocol wants come from one of two shared buffers
+    constant = {0: None, 1: None}
+
+    def payload_of(buf: np.ndarray, st) -> np.ndarray:
+        value = 0 if st.all_bytes_zero else 1 if st.all_bytes_one else None
+        if value is None:
+            return buf
+        if constant[value] is None:
+            constant[value] = np.full(CHUNK_BYTES, value, np.uint8)
+        return constant[value]
 
     threads = [threading.Thread(target=sender, daemon=True) for _ in range(max(1, senders))]
     for t in threads:
@@ -286,7 +298,7 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
             if workload is not None:
                 log("Workload received:", workload)
                 buf = free.get()
-                dev.submit_datachunk(slot, *workload, buf)
+                dev.submit_datachunk(slot, *workload, buf, lazy_uniform=True)
                 inflight[slot] = (workload, buf)
                 leased += 1
             slot ^= 1

@@ -63,6 +63,14 @@ enum mbk_status {
  * Its oracle is oracle/mandel_oracle.c:mbo_escape_f32.  Supported by the asm / group kernels. */
 #define MBK_PRECISION_F32 0x1000u
 
+/* Host-buffer calls with MBK_WANT_BYTES (bit 13): copy the quantised bytes to the host only if the tile is not
+ * uniform.  The stats reduction runs on the device anyway; when it reports all_bytes_zero ("Never",
+ * DataChunk.cs:82) or all_bytes_one ("Immediate", :87) the 16 MiB copy is skipped and h_bytes is left
+ * UNTOUCHED -- the caller takes the constant from mbk_stats.  3 tiles in 4 of a pyramid level are of that
+ * kind, and the copy (0.31 ms pinned) is 5x their kernel time.  Honoured by mbk_view_compute,
+ * mbk_view_submit and mbk_datachunk_submit_ex; the decision is made in mbk_wait. */
+#define MBK_LAZY_UNIFORM 0x2000u
+
 typedef struct mbk_ctx mbk_ctx;
 
 /*
@@ -180,6 +188,8 @@ int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, ui
 #define MBK_SLOTS 2
 int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
                          uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts);
+int mbk_datachunk_submit_ex(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
+                            uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, uint32_t flags /* MBK_LAZY_UNIFORM */);
 int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats);
 /* The same for a generic view / window (the multi-GPU shard unit is a row band of a view): enqueue on
  * `slot`, results land in h_counts / h_bytes (either may be NULL according to flags) after mbk_wait. */

@@ -38,3 +38,15 @@ for i in range(1, len(tiles) + 1):
     dev.wait((i - 1) % 2)
 dt2 = time.perf_counter() - t0
 print(f"two slots in flight: {n} tiles in {dt2:.3f} s = {n/dt2:.1f} tiles/s")
+
+# ... and without copying uniform tiles off the GPU (MBK_LAZY_UNIFORM): what the pipelined worker does
+t0 = time.perf_counter()
+skipped = 0
+dev.submit_datachunk(0, level, mrd, *tiles[0], pins[0], lazy_uniform=True)
+for i in range(1, len(tiles) + 1):
+    if i < len(tiles):
+        dev.submit_datachunk(i % 2, level, mrd, *tiles[i], pins[i % 2], lazy_uniform=True)
+    st = dev.wait((i - 1) % 2)
+    skipped += st.all_bytes_zero or st.all_bytes_one
+dt3 = time.perf_counter() - t0
+print(f"two slots in flight, uniform tiles not copied ({skipped} of {n}): {n} tiles in {dt3:.3f} s = {n/dt3:.1f} tiles/s")

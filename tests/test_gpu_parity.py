@@ -508,3 +508,21 @@ def test_default_kernel_follows_the_heavy_share_hint(oracle):
                 v, m = cases[name]
                 c, _, _ = dev.compute_view(v, m, want_bytes=False)
                 assert np.array_equal(c, want[name]), (share, name)
+
+
+def test_lazy_uniform_skips_the_copy_only_for_uniform_tiles(gpu, golden):
+    """MBK_LAZY_UNIFORM: an all-interior tile ("Never", every byte 0) leaves the host buffer untouched and says
+    so in the stats; a boundary tile is copied as usual."""
+    buf = gpu.pinned_empty((16777216,), np.uint8)
+    buf[:] = 7
+    gpu.submit_datachunk(0, 20, 1024, 7, 9, buf, lazy_uniform=True)           # golden: all 16 777 216 pixels in the set
+    st = gpu.wait(0)
+    assert st.all_bytes_zero and not st.all_bytes_one and st.d2h_ms < 0.05 and (buf == 7).all()
+    gpu.submit_datachunk(1, 4, 256, 0, 0, buf, lazy_uniform=True)             # all exterior, but bytes 1..3: not uniform
+    st = gpu.wait(1)
+    assert not st.all_bytes_zero and not st.all_bytes_one
+    assert hashlib.sha256(buf.tobytes()).hexdigest() == str(golden["full/4_256_0_0/bytes_sha256"])
+    buf[:] = 7
+    gpu.submit_datachunk(0, 16, 1024, 0, 0, buf, lazy_uniform=True)           # far corner: every pixel escapes at step 1 -> byte 1
+    st = gpu.wait(0)
+    assert st.all_bytes_one and (buf == 7).all() and st.never_pixels == 0

@@ -159,17 +159,22 @@ class _FakeDevice:
     def pinned_empty(self, shape, dtype):
         return np.empty(shape, dtype)
 
-    def submit_datachunk(self, slot, level, mrd, ir, ii, out_bytes):
+    def submit_datachunk(self, slot, level, mrd, ir, ii, out_bytes, lazy_uniform=False):
         assert self.slots[slot] is None, "slot reused before wait"
+        self.lazy = getattr(self, "lazy", 0) + int(lazy_uniform)
         self.slots[slot] = ((level, mrd, ir, ii), out_bytes)
         self.submitted.append((level, mrd, ir, ii))
         self.max_inflight = max(self.max_inflight, sum(x is not None for x in self.slots))
 
     def wait(self, slot):
         w, buf = self.slots[slot]
-        buf[:] = pattern_compute(*w)
         self.slots[slot] = None
+        if self.uniform_value is not None:     # a uniform tile: like MBK_LAZY_UNIFORM, the buffer is NOT written
+            return self._stats(0.1, 0.0, 1000, 0, self.uniform_value == 0, self.uniform_value == 1, 1)
+        buf[:] = pattern_compute(*w)
         return self._stats(0.1, 0.1, 1000, 0, False, False, 5)
+
+    uniform_value = None
 
     def close(self):
         pass
@@ -235,3 +240,16 @@ def test_main_honours_an_explicit_single_device(monkeypatch):
     assert seen == {"addr": "10.0.0.1", "port": 59010, "devices": [3]}
     worker.main(["h", "1", "0,2,5"])
     assert seen["devices"] == [0, 2, 5]
+
+
+def test_pipelined_worker_sends_constant_payload_for_uniform_tiles():
+    """Tiles the device reports as all-0 / all-1 are not copied off the GPU (MBK_LAZY_UNIFORM); the wire still
+    carries 16 777 216 bytes of that constant."""
+    for value in (0, 1):
+        with FakeDistributer([(2, 16)]) as srv:
+            dev = _FakeDevice()
+            dev.uniform_value = value
+            n = worker.run_pipelined("127.0.0.1", srv.port, device=dev, log=QUIET, senders=2)
+            assert n == 4 and srv.wait_completed(4) and dev.lazy == 4
+            for data in srv.completed.values():
+                assert data.size == CHUNK_BYTES and (data == value).all()
