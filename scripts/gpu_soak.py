@@ -1,8 +1,9 @@
-"""One-off randomized parity soak: random views x kernels x precisions against the CPU oracle.
-    timeout 900 python scripts/gpu_soak.py [seconds] [seed]"""
+"""Randomized parity soak: random views x kernels x precisions x tuning options x output sets against the CPU
+oracle (run on the GPU box).   timeout 900 python scripts/gpu_soak.py [seconds] [seed]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
+import torch
 from distributedmandelbrot_amd import MandelbrotDevice, View
 from oracle.oracle import COracle
 
@@ -10,11 +11,21 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rs = np.random.RandomState(seed)
 o = COracle()
-dev = MandelbrotDevice(0)
-combos = [("group", "f64"), ("asm", "f64"), ("refill", "f64"), ("simple", "f64"), ("group", "f32"), ("asm", "f32")]
+combos = [("scan", "f64"), ("default", "f64"), ("group", "f64"), ("asm", "f64"), ("refill", "f64"), ("simple", "f64"),
+          ("scan", "f32"), ("group", "f32"), ("asm", "f32")]
+OPTION_CHOICES = {"scan_waves": [1, 2, 8], "scan_xcd_map": [0, 1], "scan_col_period": [0, 1, 4], "group_steps": [4, 8, 16],
+                  "exact_steps": [0, 3, 8, 20], "order": [0, 1, 2], "heavy_share": [0, 655, 65536], "waves_per_wg": [1, 2, 4]}
 t0 = time.time(); n = 0; px = 0
+dev = None
 while time.time() - t0 < budget:
-    kind = rs.randint(0, 6)
+    if dev is None or n % 25 == 0:          # a fresh ctx with a random option set every 25 views
+        if dev is not None:
+            dev.close()
+        dev = MandelbrotDevice(0)
+        opts = {k: int(rs.choice(v)) for k, v in OPTION_CHOICES.items() if rs.rand() < 0.5}
+        for k, v in opts.items():
+            dev.set_option(k, v)
+    kind = rs.randint(0, 7)
     if kind == 0:
         cr, ci = rs.uniform(-2.1, 2.1), rs.uniform(-2.1, 2.1)
     elif kind == 1:
@@ -27,23 +38,40 @@ while time.time() - t0 < budget:
         cr, ci = rs.uniform(-2, 0.3), rs.choice([0.0, 1e-300, -1e-310, 1e-17])
     elif kind == 4:
         cr, ci = -0.743643 + rs.uniform(-1e-4, 1e-4), 0.131825 + rs.uniform(-1e-4, 1e-4)
+    elif kind == 5:
+        cr, ci = rs.uniform(-3, 3), rs.uniform(-3, 3)          # mostly far exterior: the light path
     else:
         th = rs.uniform(0, 2 * np.pi); cr, ci = -1 + 0.25 * np.cos(th), 0.25 * np.sin(th)
-    span_r = 10.0 ** rs.uniform(-11, 0.5); span_i = span_r * rs.uniform(0.2, 5.0)
-    w, h = int(rs.randint(1, 200)), int(rs.randint(1, 200))
-    mrd = int(rs.choice([2, 3, 8, 9, 10, 16, 17, 18, 24, 25, 26, 33, 100, 257, 1000, 4000]))
+    span_r = 10.0 ** rs.uniform(-11, 0.7); span_i = span_r * rs.uniform(0.2, 5.0)
+    big = rs.rand() < 0.25                                       # enough blocks for several sweeps of the light pass
+    w, h = (int(rs.randint(200, 1400)), int(rs.randint(200, 1100))) if big else (int(rs.randint(1, 200)), int(rs.randint(1, 200)))
+    mrd = int(rs.choice([2, 3, 4, 5, 6, 8, 9, 10, 16, 17, 18, 24, 25, 26, 33, 100, 257, 1000] + ([] if big else [4000])))
     view = View(cr - span_r / 2, ci - span_i / 2, span_r, span_i, w, h)
     window = None
     if w > 3 and h > 3 and rs.rand() < 0.3:
         c0, r0 = int(rs.randint(0, w - 1)), int(rs.randint(0, h - 1))
         window = (c0, r0, int(rs.randint(1, w - c0 + 1)), int(rs.randint(1, h - r0 + 1)))
     kernel, prec = combos[rs.randint(0, len(combos))]
-    c, b, st = dev.compute_view(view, mrd, window=window, kernel=kernel, precision=prec)
     oc, ob, total = o.view(view.start_r, view.start_i, view.range_r, view.range_i, w, h, mrd, window=window, precision=prec)
-    if not (np.array_equal(c, oc) and np.array_equal(b, ob) and st.pixel_iterations == total):
-        print("MISMATCH", kernel, prec, view, mrd, window, int((c != oc).sum()), flush=True)
-        idx = np.argwhere(c != oc)[:5]
-        print([(int(r), int(cc), int(c[r, cc]), int(oc[r, cc])) for r, cc in idx])
+    outs = rs.randint(0, 3) if kernel != "refill" else 0       # 0: host API (counts + bytes); 1: bytes only; 2: counts only
+    if outs == 0:
+        c, b, st = dev.compute_view(view, mrd, window=window, kernel=kernel, precision=prec)
+        ok = np.array_equal(c, oc) and np.array_equal(b, ob) and st.pixel_iterations == total
+    else:                                                        # device-pointer launch with a single output
+        npx = oc.size
+        t = torch.full((npx,), 77, dtype=torch.uint8 if outs == 1 else torch.int32, device="cuda:0")
+        s = torch.cuda.current_stream().cuda_stream
+        dev.launch_view(view, mrd, window=window, kernel=kernel, precision=prec, stream=s,
+                        **({"d_bytes": t.data_ptr()} if outs == 1 else {"d_counts": t.data_ptr()}))
+        torch.cuda.synchronize()
+        got = t.cpu().numpy().reshape(oc.shape)
+        c = got
+        ok = np.array_equal(got, ob if outs == 1 else oc)
+    if not ok:
+        print("MISMATCH", kernel, prec, opts, "outs", outs, view, mrd, window, flush=True)
+        ref = ob if outs == 1 else oc
+        idx = np.argwhere(c != ref)[:5]
+        print([(int(r), int(cc), int(c[r, cc]), int(ref[r, cc])) for r, cc in idx])
         sys.exit(1)
-    n += 1; px += c.size
+    n += 1; px += oc.size
 print(f"soak ok: {n} random views, {px/1e6:.1f} Mpixel, {time.time()-t0:.0f} s, seed {seed}")
