@@ -11,7 +11,7 @@ For N > 1 the driver launches one rank per GPU (torch.distributed.run); tiles ar
 every rank computes its own tile with no data-path collective ("weak" scaling); the only
 communication is the barrier and the max-over-ranks of the elapsed time, on gloo (CPU tensors) -- there
 is no RCCL anywhere (`--control nccl` exists to A/B that choice).  `--shard bands` is the strong-scaling
-form BASELINE cfg3 asks for: ONE view per step, cut into >= 16 row bands per GPU which the ranks pull
+form BASELINE cfg3 asks for: ONE view per step, cut into >= 16 row bands per GPU (of >= 128 rows) which the ranks pull
 from a cursor in shared memory (distributedmandelbrot_amd.sharding.SharedCursor; dynamic, because band
 cost varies >100x), two bands in flight per GPU.
 
@@ -101,7 +101,7 @@ def parse_args():
                     help="tiles (default): every rank computes its own tile per step (weak scaling). bands: ONE "
                          "view per step, cut into >= 16 row bands per GPU that the ranks pull from a shared-memory "
                          "cursor (strong scaling; how BASELINE cfg3 shards an image over 8 GPUs)")
-    ap.add_argument("--band-rows", type=int, default=0, help="rows per band for --shard bands (default: height / (16 N), >= 8)")
+    ap.add_argument("--band-rows", type=int, default=0, help="rows per band for --shard bands (default: height / (16 N), >= 128)")
     ap.add_argument("--streams", type=int, default=None,
                     help="tiles (or bands) in flight per GPU (default 1 for tiles = the contract's serial steps, 2 for bands)")
     ap.add_argument("--control", default="gloo", choices=["gloo", "nccl"],
@@ -228,7 +228,10 @@ def main():
             dist.barrier()
 
     nstreams = max(1, args.streams)
-    band_rows = args.band_rows or max(8, height // (16 * world))
+    # >= 16 bands per GPU, but no band under 128 rows: a band costs ~70 us of host work (cursor lock, two kernel
+    # launches, an event), which must stay below its GPU time.  Tickets run on across steps (no barrier
+    # between images), so the tail that larger bands leave idle is paid once per run, not once per image.
+    band_rows = args.band_rows or max(128, height // (16 * world))
     band_rows = max(8, (band_rows // 8) * 8)
     from distributedmandelbrot_amd.sharding import SharedCursor, make_bands
     bands = make_bands(height, band_rows) if bands_mode else None
@@ -271,7 +274,8 @@ def main():
         d_smooth_all = [torch.empty(npix, dtype=torch.float64, device=f"cuda:{local_rank}") for _ in range(nbuf)] if smooth else None
         d_bytes_all = [torch.empty(npix, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(nbuf)] if args.outputs == "both" else None
         streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
-        slot_events = [None] * nstreams
+        slot_events = [torch.cuda.Event() for _ in range(nstreams)]
+        slot_busy = [False] * nstreams
 
         def launch_tile(i):
             if smooth:
@@ -286,14 +290,13 @@ def main():
             dev.launch_view(view, mrd, window=(0, bnd.row0, width, bnd.nrows),
                             d_counts=d_counts_all[0].data_ptr() + 4 * bnd.row0 * width,
                             stream=streams[i].cuda_stream, kernel=args.kernel, precision=args.precision)
-            ev = torch.cuda.Event()
-            ev.record(streams[i])
-            slot_events[i] = ev
+            slot_events[i].record(streams[i])
+            slot_busy[i] = True
 
         def slot_wait(i):          # back-pressure: one band in flight per slot, or a rank would drain the cursor
-            if slot_events[i] is not None:
+            if slot_busy[i]:
                 slot_events[i].synchronize()
-                slot_events[i] = None
+                slot_busy[i] = False
 
         def sync():
             torch.cuda.synchronize()

@@ -2,9 +2,10 @@
 
 The escape-time path has no exchange step (every pixel depends only on its own c), so there is no
 collective: the shard unit is a contiguous band of rows of the view (contiguous in the output, one
-D2H per band).  Cost per band varies by >100x (in-set vs far exterior), hence dynamic assignment
-from one shared cursor when the GPUs live in one process (`render_view`), and an interleaved static
-assignment when there is one process per GPU (`rank_bands`, used by bench.py under torchrun).
+D2H per band).  Cost per band varies by >100x (in-set vs far exterior), hence dynamic assignment from
+one shared cursor: `WorkQueue` when the GPUs live in one process (`render_view`), `SharedCursor` (an
+int64 in /dev/shm under an fcntl lock) when there is one process per GPU (bench.py --shard bands under
+torchrun).  `rank_bands` is the static interleaved split, kept for callers that cannot share a cursor.
 
 The reference shards the same way one level up: the Distributer leases whole 4096x4096 tiles to
 whichever worker asks next (Distributer.cs:335-353).

@@ -153,7 +153,7 @@ def test_bench_bands_dynamic_cursor_gloo_world2():
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     cfg = rec["config"]
     assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and cfg["control_backend"] == "gloo"
-    assert cfg["bands_per_image"] == 32 and cfg["band_rows"] == 256          # >= 16 bands per GPU
+    assert cfg["bands_per_image"] == 32 and cfg["band_rows"] == 256          # >= 16 bands per GPU (of >= 128 rows)
     assert cfg["bands_exactly_once"] is True
     assert sum(cfg["bands_per_rank"]) == 3 * 32 and min(cfg["bands_per_rank"]) > 0
     assert not os.path.exists(os.path.join("/dev/shm", "mbk_cursor_%d_none" % port))
