@@ -32,6 +32,13 @@ figure.  `traffic` is HBM bytes per launch from separate `rocprofv3 --pmc` passe
 (committed under profiles/, see `traffic_source`); counters cannot be read from inside the run.
 `cpu_baseline`: the strict-IEEE C oracle (oracle/, kind "port": the reference has no CPU
 implementation and its numba path cannot run here) on the host cores, rank 0, N = 1 only.
+
+Cycle test: the library's default (MBK_OPT_CYCLE_DETECT = 1) retires a pixel as "never escapes" as soon as
+its (zr, zi) bit pattern repeats -- bit-identical counts, but iterations the reference would run are not
+executed.  `value` and `roofline` are therefore measured with the test OFF (every iteration executed; stated
+in config.cycle_test); the same K steps with the default ON are timed right after in the same run and
+reported as the extra object `cycle_detection` (reference-equivalent rate, ms per step, speed-up).
+`--opt cycle_detect=1` moves the test into the headline, labelled as such.
 """
 from __future__ import annotations
 
@@ -264,6 +271,11 @@ def main():
         from distributedmandelbrot_amd import MandelbrotDevice, View
         torch.cuda.set_device(local_rank)
         dev = MandelbrotDevice(local_rank)   # raises loudly without the HIP library / a gfx950 GPU
+        # The headline is measured with the cycle test OFF: every iteration the reference would run is executed, so
+        # `value` and the roofline describe the loop itself.  The library's default (ON: bit-identical counts, exactly
+        # periodic orbits retired early) is timed in the same run as the extra object "cycle_detection".
+        if "cycle_detect" not in options:
+            dev.set_option("cycle_detect", 0)
         for k, v in options.items():
             dev.set_option(k, v)
         device_info = dev.info()
@@ -362,11 +374,31 @@ def main():
         iters_per_step, never = st.pixel_iterations, st.never_pixels
         kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
 
+    # second leg (tiles mode, fp64/fp32 count kernels): the same K steps with the library's default cycle test
+    cyc_leg = None
+    if not fake and not bands_mode and "cycle_detect" not in options and args.kernel in ("default", "group", "scan"):
+        dev.set_option("cycle_detect", 1)
+        run_steps(max(args.warmup, 2))
+        sync()
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(args.steps)
+        sync()
+        barrier()
+        cyc_elapsed = time.perf_counter() - t1
+        st2 = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
+        cyc_leg = (cyc_elapsed, st2.pixel_iterations == iters_per_step and st2.never_pixels == never)
+        dev.set_option("cycle_detect", 0)
+
     bands_once = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_max = float(t.item())
+        if cyc_leg is not None:
+            t = torch.tensor([cyc_leg[0]], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cyc_leg = (float(t.item()), cyc_leg[1])
         if bands_mode:
             gathered = [None] * world
             dist.all_gather_object(gathered, my_tickets)
@@ -394,6 +426,8 @@ def main():
         slots = VALU_SLOTS_PER_PIXEL_ITER.get(args.kernel, 8.0)
         if args.kernel in ("default", "scan", "group") and options.get("group_steps", 16) != 16:
             slots = 6.25 if options["group_steps"] == 8 else 6.5
+        if options.get("cycle_detect", 0) and args.kernel in ("default", "scan", "group") and options.get("group_steps", 16) != 4:
+            slots += 0.125     # two bitwise state compares per 16 steps
         out_bytes = npix * (12 if smooth else 4)
         traffic, traffic_source = pmc_traffic(args.workload, args.kernel) if args.precision == "f64" and not options else (None, None)
         metric = "G pixel-iterations/s on 4096^2 tile, max_iter=1000 fp64"
@@ -401,6 +435,9 @@ def main():
                    f"one image per step cut into {len(bands)} row bands of {band_rows} rows pulled from a shared cursor"
                    if bands_mode else "one tile per GPU per step") + ", int32 counts written to resident HBM",
                "kernel": args.kernel, "options": options, "outputs": args.outputs,
+               "cycle_test": ("on (--opt)" if options.get("cycle_detect", 0) else
+                              "off for value and roofline: every iteration the reference runs is executed" +
+                              ("; the library default (on) is timed in this run: see cycle_detection" if cyc_leg else "")),
                "pixels_per_step": npix * (1 if bands_mode else world), "pixel_iterations_per_step_per_gpu": per_gpu_iters,
                "never_escaped_pixels": never, "parallelism": f"{world} independent work queue(s), no collective",
                "streams_per_gpu": nstreams, "shard": args.shard, "control_backend": backend,
@@ -444,6 +481,17 @@ def main():
                 "hbm_GBps": out_bytes / avg_kernel_s / 1e9,
             },
         }
+        if cyc_leg is not None:
+            rec["cycle_detection"] = {
+                "what": "same workload and steps with MBK_OPT_CYCLE_DETECT=1 (library default): pixels whose (zr, zi) bit "
+                        "pattern repeats are retired as 'never escapes' -- identical counts, fewer executed steps; value "
+                        "counts the reference's iterations, not the executed ones",
+                "value": iters_all * args.steps / cyc_leg[0] / 1e9,
+                "unit": "G pixel-iterations/s (reference-equivalent)",
+                "ms_per_step": cyc_leg[0] / args.steps * 1e3,
+                "speedup_vs_strict": elapsed_max / cyc_leg[0],
+                "same_pixel_iterations_and_never_count": bool(cyc_leg[1]),
+            }
         if world == 1 and not args.no_cpu_baseline and not fake:
             rec["cpu_baseline"] = cpu_baseline(args.workload, workload, args.precision)
         elif world == 1 and fake:

@@ -220,6 +220,13 @@ static int get_scratch(mbk_ctx *ctx, hipStream_t stream, StreamScratch **out)
     return MBK_OK;
 }
 
+// Window-dependent launch facts the kernels rely on (computed for the window a launch ACTUALLY covers: the
+// edge strips of launch_refill and the bands of a view are windows of their own):
+//   fast_bx_end / fast_by_end   leading whole 8x8 blocks that hold no pinned last sample (TileArgs comment);
+//   ring_possible               conservative rectangle test against | |c|^2 - 4 | < margin (kernel margins are
+//                               1e-9 fp64 / 1e-3 fp32 per pixel; the host test allows 1e-6 / 2e-3).
+static void set_window_facts(TileArgs &a, bool f32);
+
 // Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
 // (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
 static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, bool f32, hipStream_t stream)
@@ -227,11 +234,14 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     const uint32_t wpw = ctx->opt[MBK_OPT_WAVES_PER_WG];  // 8x8-pixel blocks (= waves) per workgroup
     a.blocks_x = (a.ncols + 8u * wpw - 1u) / (8u * wpw);
     const uint32_t by = (a.nrows + 7u) / 8u;
+    set_window_facts(a, f32);
+    const bool cyc = ctx->opt[MBK_OPT_CYCLE_DETECT] != 0u;
     const dim3 grid(a.blocks_x * by), block(64u * wpw);
     const uint32_t order_mode = ctx->opt[MBK_OPT_ORDER], probe_steps = ctx->opt[MBK_OPT_PROBE_STEPS];
     a.perm_mul = order_mode == 1 ? coprime_multiplier(grid.x) : 1u;
     a.order = nullptr;
-    if (order_mode == 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps) {
+    if (order_mode == 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps && a.blocks_x <= 0xffffu && by <= 0xffffu) {
+        // (a list entry packs block row and workgroup column into 16 bits each; wider windows go in image order)
         // heavy-first dispatch order (see classify_blocks_kernel); small launches skip it: one kernel in image
         // order beats memset + classify + tile below ~16 k blocks (cfg1, 4096 blocks: 20 us against 27)
         StreamScratch *sc = nullptr;
@@ -260,14 +270,20 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, 0, stream, a);
     else if (f32 && kernel == MBK_KERNEL_ASM)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, 0, stream, a);
+    else if (f32 && cyc)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8, true>), grid, block, 0, stream, a);
     else if (f32)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, 0, stream, a);
     else if (safe)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, 0, stream, a);
     else if (kernel == MBK_KERNEL_ASM)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, 0, stream, a);
+    else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 16 && cyc)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16, true>), grid, block, 0, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 16)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16>), grid, block, 0, stream, a);
+    else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 8 && cyc)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8, true>), grid, block, 0, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 8)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, 0, stream, a);
     else
@@ -287,6 +303,18 @@ static bool window_may_touch_ring(const TileArgs &a, double margin = 1e-6)
     const double fx = std::fmax(std::fabs(xlo), std::fabs(xhi)), fy = std::fmax(std::fabs(ylo), std::fabs(yhi));
     const double rmin2 = dx * dx + dy * dy, rmax2 = fx * fx + fy * fy;
     return !(rmax2 < 4.0 - margin || rmin2 > 4.0 + margin);
+}
+
+static void set_window_facts(TileArgs &a, bool f32)
+{
+    a.ring_possible = window_may_touch_ring(a, f32 ? 2e-3 : 1e-6) ? 1u : 0u;
+    a.fast_bx_end = a.fast_by_end = 0u;
+    if (a.re.step_is_zero || a.im.step_is_zero) return;
+    // window columns / rows before the axis' last sample (col0 + ncols <= n: validate_view)
+    const uint64_t cols_ok = std::min<uint64_t>(a.ncols, (uint64_t)a.re.n - 1u - std::min<uint64_t>(a.col0, (uint64_t)a.re.n - 1u));
+    const uint64_t rows_ok = std::min<uint64_t>(a.nrows, (uint64_t)a.im.n - 1u - std::min<uint64_t>(a.row0, (uint64_t)a.im.n - 1u));
+    a.fast_bx_end = (uint32_t)(cols_ok / 8u);
+    a.fast_by_end = (uint32_t)(rows_ok / 8u);
 }
 
 // Kernel "refill": persistent lane-refill kernel on the interior blocks + "group" on the edge strips.
@@ -430,14 +458,17 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     if (s.ranks2 == 0u) s.ranks2 = 1u;
     s.hint_out = sc->h_hint;
     s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] == 16u ? 1u : 0u;
-    a.ring_possible = window_may_touch_ring(a, f32 ? 2e-3 : 1e-6) ? 1u : 0u;
+    set_window_facts(a, f32);
     if (a.counts && a.bytes)
         hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, true>), dim3(w1), dim3(64), 0, stream, a, s);
     else if (a.bytes)
         hipLaunchKernelGGL((mbk::tile_light_kernel<T, false, true>), dim3(w1), dim3(64), 0, stream, a, s);
     else
         hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, false>), dim3(w1), dim3(64), 0, stream, a, s);
-    hipLaunchKernelGGL(mbk::tile_todo_kernel<T>, dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
+    if (ctx->opt[MBK_OPT_CYCLE_DETECT] != 0u)
+        hipLaunchKernelGGL((mbk::tile_todo_kernel<T, true>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
+    else
+        hipLaunchKernelGGL((mbk::tile_todo_kernel<T, false>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
     MBK_HIP(ctx, hipGetLastError());
     return MBK_OK;
 }
@@ -596,7 +627,7 @@ int mbk_create(int device, mbk_ctx **out)
     static const uint32_t kDefaults[MBK_OPT_COUNT_] = {
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
-        /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u};
+        /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -972,6 +1003,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_RF_PATIENCE: ok = value >= 16u && value <= (1u << 20); break;
         case MBK_OPT_RF_BATCH: ok = value >= 1u && value <= 64u; break;
         case MBK_OPT_RF_WAVES: ok = value >= 1u && value <= 8u; break;
+        case MBK_OPT_CYCLE_DETECT: ok = value <= 1u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

@@ -45,9 +45,13 @@ struct TileArgs {
     uint32_t quant_wide;  // 1: count*256+mrd-1 does not fit 32 bits -> 64-bit quantiser division
     double quant_rcp;     // fl(1/mrd), host-computed: the narrow quantiser divides by multiplying (see quantise)
     uint32_t exact_steps; // steps tested one by one before the grouped test takes over
-    uint32_t ring_possible;  // scan: 0 = the host proved that no pixel of the window lies near |c| = 2
+    uint32_t ring_possible;  // 0 = the host proved that no pixel of the window lies near |c| = 2
+    uint32_t fast_bx_end, fast_by_end;  // 8x8 blocks with column index < fast_bx_end and row index < fast_by_end
+                          // lie wholly inside the window, hold neither axis' pinned last sample, and both steps
+                          // are non-zero: their coordinates are fl(fl(k*step)+start), no per-lane edge handling
     uint32_t perm_mul;    // workgroup order: block = (blockIdx * perm_mul) mod gridDim (1 = row-major)
-    const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel)
+    const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel); an entry is
+                           // (block row << 16) | workgroup column -- the host offers it only when both fit 16 bits
     uint32_t *heavy_hint;  // optional, pinned host memory: with `order`, workgroup 0 reports the share of
                            // probe-heavy regions (x 65536) -- next launch's kernel choice (mbk_api.hip)
     int32_t *counts;      // may be null
@@ -160,46 +164,71 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
 #define MBK_T double
 #define MBK_F "f64"
 #define MBK_CI_FROM_T64 "v_add_f64 %[ci], %[t64], %[start]\n"
+#define MBK_CYC_BITS "u64"   // bitwise state compare / copy of the cycle test
+#define MBK_CYC_MOV "b64"
 #include "mbk_loops.inc"
 #undef MBK_T
 #undef MBK_F
 #undef MBK_CI_FROM_T64
+#undef MBK_CYC_BITS
+#undef MBK_CYC_MOV
 #define MBK_T float
 #define MBK_F "f32"
 #define MBK_CI_FROM_T64 "v_add_f64 %[t64], %[t64], %[start]\nv_cvt_f32_f64 %[ci], %[t64]\n"
+#define MBK_CYC_BITS "u32"
+#define MBK_CYC_MOV "b32"
 #include "mbk_loops.inc"
 #undef MBK_T
 #undef MBK_F
 #undef MBK_CI_FROM_T64
+#undef MBK_CYC_BITS
+#undef MBK_CYC_MOV
 
 
 // One pixel of an 8x8 block, start to finish (one lane each; the whole wave calls it): coordinates, the
 // escape loop of the chosen kind, the stores.  T = double: the reference's arithmetic.  T = float: the fp32
 // variant (coordinates are generated in fp64 exactly as for the fp64 path and then rounded once to fp32; the
 // loop is strict fp32).  long_groups (wave-uniform, kGroup == 16 only): 16-step groups for this block.
-template <typename T, bool kFmaDouble, int kGroup>
-__device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint32_t lr, bool long_groups)
+// interior (wave-uniform): the block lies inside TileArgs::fast_bx_end / fast_by_end -- no lane is outside the
+// window or on an axis' pinned end point, so the coordinates need no per-lane selects, and when the host has
+// also ruled out the |c| = 2 ring for the whole window the per-wave ring test goes too (~20 of the ~57 VALU
+// instructions a block costs outside its loop; on cfg2 that overhead is 15 M of 317 M instructions).
+// kCycle: the grouped loops retire exactly periodic orbits early (mbk_loops.inc, MBK_G_CYC).
+template <typename T, bool kFmaDouble, int kGroup, bool kCycle = false>
+__device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint32_t lr, bool long_groups,
+                                            bool interior = false)
 {
-    if (lc >= p.ncols || lr >= p.nrows) return;
-    const T cr = (T)axis_value(p.re, p.col0 + lc);
-    const T ci = (T)axis_value(p.im, p.row0 + lr);
+    T cr, ci;
+    bool ring_test = kGroup != 0 && kFmaDouble;
+    if (interior) {
+        cr = (T)((double)(p.col0 + lc) * p.re.step + p.re.start);
+        ci = (T)((double)(p.row0 + lr) * p.im.step + p.im.start);
+        ring_test = ring_test && p.ring_possible != 0u;
+    } else {
+        if (lc >= p.ncols || lr >= p.nrows) return;
+        cr = (T)axis_value(p.re, p.col0 + lc);
+        ci = (T)axis_value(p.im, p.row0 + lr);
+    }
     int32_t count;
     T m = 0;  // |z|^2 at the escaping step (only meaningful when count > 0)
     if (kGroup != 0 && kFmaDouble) {
         // the grouped test relies on "|z|^2 >= 4 stays >= 4"; only |c| within rounding of 2 could
         // spoil that, so any wave touching that ring takes the per-step loop (wave-uniform branch)
-        const T c2 = cr * cr + ci * ci;
-        const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
-        const bool risky = __any(c2 > (T)4 - margin && c2 < (T)4 + margin) != 0;
+        bool risky = false;
+        if (ring_test) {
+            const T c2 = cr * cr + ci * ci;
+            const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
+            risky = __any(c2 > (T)4 - margin && c2 < (T)4 + margin) != 0;
+        }
         if (risky) {
             count = escape_count_asm<true>(cr, ci, p.mrd, &m);
         } else if (kGroup == 16) {
             // 16-step groups (6.125 issue slots per step) only where the test hardly ever trips (interior of
             // the set: the blocks a probe or the light pass classified as such); 8 elsewhere
-            count = long_groups ? escape_count_group<16>(cr, ci, p.mrd, &m, p.exact_steps)
-                                : escape_count_group<8>(cr, ci, p.mrd, &m, p.exact_steps);
+            count = long_groups ? escape_count_group<16, kCycle>(cr, ci, p.mrd, &m, p.exact_steps)
+                                : escape_count_group<8, kCycle>(cr, ci, p.mrd, &m, p.exact_steps);
         } else {
-            count = escape_count_group<kGroup == 8 ? 8 : 4>(cr, ci, p.mrd, &m, p.exact_steps);
+            count = escape_count_group<kGroup == 8 ? 8 : 4, kCycle>(cr, ci, p.mrd, &m, p.exact_steps);
         }
     } else {
         count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd, &m);
@@ -211,23 +240,32 @@ __device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint
 }
 
 // Kernels "asm" (kGroup = 0) and "group": one 8x8 block per wave, blockDim / 64 blocks per workgroup.
-template <typename T, bool kFmaDouble, int kGroup = 0>
+template <typename T, bool kFmaDouble, int kGroup = 0, bool kCycle = false>
 __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // Dispatch order != image order when an order list is given (heavy-first, classify_blocks_kernel)
     // or perm_mul != 1 (multiplicative permutation, coprime to the grid size).
-    const uint32_t blk = p.order ? p.order[blockIdx.x]
-                                 : (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
-    if (p.order && p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)   // cursors sit behind the list
-        *p.heavy_hint = (uint32_t)(((uint64_t)p.order[gridDim.x] << 16) / gridDim.x);
-    const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
-    const uint32_t lc = (bx * (blockDim.x >> 6) + wave) * 8u + (lane & 7u);  // one 8x8 block per wave
+    uint32_t bx, by;
+    if (p.order) {
+        const uint32_t e = p.order[blockIdx.x];   // packed by the classify kernel: no division here
+        by = e >> 16;
+        bx = e & 0xffffu;
+        if (p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)   // cursors sit behind the list
+            *p.heavy_hint = (uint32_t)(((uint64_t)p.order[gridDim.x] << 16) / gridDim.x);
+    } else {
+        const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
+        by = blk / p.blocks_x;
+        bx = blk - by * p.blocks_x;
+    }
+    const uint32_t wcol = bx * (blockDim.x >> 6) + wave;  // one 8x8 block per wave
+    const uint32_t lc = wcol * 8u + (lane & 7u);
     const uint32_t lr = by * 8u + (lane >> 3);
     // the blocks the heavy-first probe put at the front of the dispatch order take the 16-step groups
     const bool long_groups = kGroup == 16 && (!p.order || blockIdx.x < p.order[gridDim.x]);   // wave-uniform
-    block_pixel<T, kFmaDouble, kGroup>(p, lc, lr, long_groups);
+    const bool interior = wcol < p.fast_bx_end && by < p.fast_by_end;                        // wave-uniform
+    block_pixel<T, kFmaDouble, kGroup, kCycle>(p, lc, lr, long_groups, interior);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -250,8 +288,10 @@ __global__ __launch_bounds__(1024) void classify_blocks_kernel(TileArgs p, uint3
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     bool valid = r < nregions, heavy = false;
+    uint32_t packed = 0;   // the list entry of this region: (block row << 16) | workgroup column
     if (valid) {
         const uint32_t by = r / p.blocks_x, bx = r - by * p.blocks_x;
+        packed = (by << 16) | bx;
         uint32_t lc = bx * region_w + region_w / 2u, lr = by * 8u + 4u;
         lc = lc < p.ncols ? lc : p.ncols - 1u;
         lr = lr < p.nrows ? lr : p.nrows - 1u;
@@ -282,9 +322,9 @@ __global__ __launch_bounds__(1024) void classify_blocks_kernel(TileArgs p, uint3
     if (valid) {
         const unsigned long long below = (1ull << lane) - 1ull;
         if (heavy)
-            order[s_base[0] + s_heavy[wave] + (uint32_t)__popcll(hm & below)] = r;
+            order[s_base[0] + s_heavy[wave] + (uint32_t)__popcll(hm & below)] = packed;
         else
-            order[nregions - 1u - (s_base[1] + s_light[wave] + (uint32_t)__popcll(lm & below))] = r;
+            order[nregions - 1u - (s_base[1] + s_light[wave] + (uint32_t)__popcll(lm & below))] = packed;
     }
 }
 

@@ -232,6 +232,10 @@ enum mbk_option {
     MBK_OPT_RF_PATIENCE,   /* refill: steps between forced refill checks: 16..2^20 [256] */
     MBK_OPT_RF_BATCH,      /* refill: blocks per queue pop: 1..64 [1] */
     MBK_OPT_RF_WAVES,      /* refill: resident waves per SIMD: 1..[8] */
+    MBK_OPT_CYCLE_DETECT,  /* group / scan pass 2 (8- and 16-step groups): retire a pixel as "never escapes" as soon as its
+                              (zr, zi) bit pattern repeats an earlier state of its own orbit -- the step map is a
+                              deterministic function of those bits, so the reference's loop provably runs to mrd-1 and
+                              returns 0.  Same counts, fewer executed steps on tiles that hold part of the set: 0, [1] */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

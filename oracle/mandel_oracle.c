@@ -168,6 +168,74 @@ uint64_t mbo_view_contracted(double start_r, double start_i, double range_r, dou
     return total;
 }
 
+/* What-if model of the GPU kernels' cycle test (MBK_OPT_CYCLE_DETECT; NOT in the reference, and not an oracle:
+ * tests use it to check the CLAIM the kernels rely on, and scripts/cycle_model.py to count the steps saved).
+ * The reference loop as in mbo_escape; after the first `first` steps, every `check` steps the state (zr, zi) is
+ * compared BITWISE with a saved state, which is replaced after 1, 2, 4, 8, ... comparisons (Brent).  The step
+ * map is a function of those bits, so an exact repeat means the orbit is periodic, every state of the period
+ * has already passed the bailout test, and the reference's loop would run to mrd-1 and return 0: the model
+ * stops there.  Returns the count; *executed = steps actually run (== the reference's unless it stopped early). */
+int32_t mbo_escape_cycle(double cr, double ci, int32_t mrd, int32_t first, int32_t check, int32_t *executed)
+{
+    double zr = cr, zi = ci, sr = 0.0, si = 0.0;
+    int have = 0;
+    uint32_t tc = 0, win = 1;
+    int32_t n;
+    for (n = 1; n < mrd; ++n) {
+        double a = zr * zr;
+        double b = zi * zi;
+        double t = a - b;
+        double w = 2.0 * zr;
+        double u = w * zi;
+        zr = t + cr;
+        zi = u + ci;
+        double m = zr * zr + zi * zi;
+        if (m >= 4.0) {
+            *executed = n;
+            return n;
+        }
+        if (n >= first && check > 0 && (n - first) % check == 0) {
+            uint64_t br, bi, bsr, bsi;
+            __builtin_memcpy(&br, &zr, 8);
+            __builtin_memcpy(&bi, &zi, 8);
+            __builtin_memcpy(&bsr, &sr, 8);
+            __builtin_memcpy(&bsi, &si, 8);
+            if (!have) {  /* the kernels take the first reference state when the grouped loop starts */
+                sr = zr, si = zi, have = 1;
+            } else {
+                if (br == bsr && bi == bsi) {
+                    *executed = n;
+                    return 0;
+                }
+                if (++tc >= win) sr = zr, si = zi, tc = 0, win *= 2u;
+            }
+        }
+    }
+    *executed = mrd > 1 ? mrd - 1 : 0;
+    return 0;
+}
+
+/* counts and executed steps of a whole view under the model above (row-parallel) */
+void mbo_view_cycle(double start_r, double start_i, double range_r, double range_i, uint32_t width, uint32_t height,
+                    int32_t mrd, int32_t first, int32_t check, int32_t *counts, int32_t *executed, int nthreads)
+{
+    double *xr = (double *)malloc(sizeof(double) * (width ? width : 1));
+    double *xi = (double *)malloc(sizeof(double) * (height ? height : 1));
+    mbo_axis(start_r, range_r, width, xr);
+    mbo_axis(start_i, range_i, height, xi);
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#else
+    (void)nthreads;
+#endif
+    for (int64_t r = 0; r < (int64_t)height; ++r)
+        for (uint32_t c = 0; c < width; ++c)
+            counts[(size_t)r * width + c] = mbo_escape_cycle(xr[c], xi[r], mrd, first, check, &executed[(size_t)r * width + c]);
+    free(xr);
+    free(xi);
+}
+
 /* BASELINE config 5 (NOT in the reference): continuous escape-time value at the reference's bailout.
  * Runs the reference loop, keeps |z|^2 of the escaping step, nu = n + 1 - log2(0.5 * ln |z_n|^2); 0 if the
  * pixel never escapes.  *count_out receives the integer escape index. */

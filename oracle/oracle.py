@@ -62,6 +62,9 @@ class COracle:
         L.mbo_view_contracted.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
                                           C.c_int32, C.c_void_p, C.c_int]
         L.mbo_view_contracted.restype = C.c_uint64
+        L.mbo_view_cycle.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
+        L.mbo_view_cycle.restype = None
         L.mbo_max_threads.restype = C.c_int
         L.mbo_have_avx512.restype = C.c_int
         L.mbo_view_avx512.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
@@ -113,6 +116,15 @@ class COracle:
         counts = np.empty((height, width), np.int32)
         self.lib.mbo_view_contracted(start_r, start_i, range_r, range_i, width, height, mrd, counts.ctypes.data, nthreads)
         return counts
+
+    def view_cycle(self, start_r, start_i, range_r, range_i, width, height, mrd, *, first=8, check=16, nthreads=0):
+        """Model of the GPU kernels' cycle test (see mbo_escape_cycle): (counts, executed steps per pixel).  A what-if
+        for tests of the claim and for scripts/cycle_model.py, not the oracle."""
+        counts = np.empty((height, width), np.int32)
+        executed = np.empty((height, width), np.int32)
+        self.lib.mbo_view_cycle(start_r, start_i, range_r, range_i, width, height, mrd, first, check,
+                                counts.ctypes.data, executed.ctypes.data, nthreads)
+        return counts, executed
 
     def have_avx512(self) -> bool:
         return bool(self.lib.mbo_have_avx512())

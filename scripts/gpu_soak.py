@@ -14,7 +14,8 @@ o = COracle()
 combos = [("scan", "f64"), ("default", "f64"), ("group", "f64"), ("asm", "f64"), ("refill", "f64"), ("simple", "f64"),
           ("scan", "f32"), ("group", "f32"), ("asm", "f32")]
 OPTION_CHOICES = {"scan_waves": [1, 2, 8], "scan_xcd_map": [0, 1], "scan_col_period": [0, 1, 4], "group_steps": [4, 8, 16],
-                  "exact_steps": [0, 3, 8, 20], "order": [0, 1, 2], "heavy_share": [0, 655, 65536], "waves_per_wg": [1, 2, 4]}
+                  "exact_steps": [0, 3, 8, 20], "order": [0, 1, 2], "heavy_share": [0, 655, 65536], "waves_per_wg": [1, 2, 4],
+                  "cycle_detect": [0, 1]}
 t0 = time.time(); n = 0; px = 0
 dev = None
 while time.time() - t0 < budget:
@@ -45,7 +46,7 @@ while time.time() - t0 < budget:
     span_r = 10.0 ** rs.uniform(-11, 0.7); span_i = span_r * rs.uniform(0.2, 5.0)
     big = rs.rand() < 0.25                                       # enough blocks for several sweeps of the light pass
     w, h = (int(rs.randint(200, 1400)), int(rs.randint(200, 1100))) if big else (int(rs.randint(1, 200)), int(rs.randint(1, 200)))
-    mrd = int(rs.choice([2, 3, 4, 5, 6, 8, 9, 10, 16, 17, 18, 24, 25, 26, 33, 100, 257, 1000] + ([] if big else [4000])))
+    mrd = int(rs.choice([2, 3, 4, 5, 6, 8, 9, 10, 16, 17, 18, 24, 25, 26, 33, 41, 57, 100, 257, 1000] + ([] if big else [4000, 20000])))
     view = View(cr - span_r / 2, ci - span_i / 2, span_r, span_i, w, h)
     window = None
     if w > 3 and h > 3 and rs.rand() < 0.3:

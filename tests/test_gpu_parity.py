@@ -398,6 +398,8 @@ OPTION_MATRIX = [
     ("group", {"order": 1}), ("group", {"probe_steps": 2}), ("asm", {"waves_per_wg": 4, "order": 0}),
     ("refill", {"rf_livemin": 0}), ("refill", {"rf_livemin": 63, "rf_patience": 16}),
     ("refill", {"rf_batch": 4, "rf_waves": 2}),
+    ("group", {"cycle_detect": 0}), ("scan", {"cycle_detect": 0}), ("default", {"cycle_detect": 0}),
+    ("group", {"cycle_detect": 0, "group_steps": 8, "waves_per_wg": 2}), ("group", {"cycle_detect": 1, "exact_steps": 0, "order": 0}),
 ]
 
 
@@ -526,3 +528,59 @@ def test_lazy_uniform_skips_the_copy_only_for_uniform_tiles(gpu, golden):
     gpu.submit_datachunk(0, 16, 1024, 0, 0, buf, lazy_uniform=True)           # far corner: every pixel escapes at step 1 -> byte 1
     st = gpu.wait(0)
     assert st.all_bytes_one and (buf == 7).all() and st.never_pixels == 0
+
+
+CYCLE_VIEWS = [
+    (View(-0.2, -0.1, 0.2, 0.2, 256, 256), 5000),        # inside the main cardioid: every orbit settles on a fixed point
+    (View(-1.1, -0.1, 0.2, 0.2, 200, 200), 3000),        # period-2 bulb around c = -1 (c = -1 itself: 0, -1, 0, -1, ...)
+    (View(-0.16, 0.70, 0.08, 0.08, 160, 160), 4000),     # period-3 bulb
+    (View(0.20, -0.05, 0.10, 0.10, 128, 128), 2000),     # the cusp at 1/4: parabolic, hardly any orbit becomes periodic
+    (View(-2.0, -1.5, 3.0, 3.0, 512, 512), 3000),        # the whole set
+    (View(-1.79, -0.03, 0.06, 0.06, 96, 96), 6000),      # the period-3 minibrot on the real axis
+    (View(0.0, 0.0, 0.0, 0.0, 9, 9), 100000),            # c = 0 everywhere: fixed from the first step (step-0 linspace)
+    (View(-0.5, -0.5, 0.5, 0.5, 517, 203), 1000),        # ragged edges + pinned end points around interior blocks
+]
+
+
+_ORACLE_MEMO = {}
+
+
+def _oracle_view_memo(oracle, view, mrd, precision):
+    key = (view, mrd, precision)
+    if key not in _ORACLE_MEMO:
+        _ORACLE_MEMO[key] = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height,
+                                        mrd, precision=precision)
+    return _ORACLE_MEMO[key]
+
+
+@pytest.mark.parametrize("kernel", ["default", "group", "scan"])
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_cycle_detection_is_bit_exact(oracle, kernel, precision):
+    """MBK_OPT_CYCLE_DETECT retires a pixel as 'never escapes' when its (zr, zi) bit pattern repeats.  Same counts as
+    the strict loop (WorkerCUDA.py:39-68 runs such a pixel to mrd-1 and returns 0) on views made of set interior,
+    for both settings, for every group size with a cycle test, and for mrd values around the loops' trip limits."""
+    from distributedmandelbrot_amd import MandelbrotDevice
+    for cyc, opts in ((1, {}), (1, {"group_steps": 8}), (0, {})):
+        with MandelbrotDevice(0) as dev:
+            dev.set_option("cycle_detect", cyc)
+            for k, v in opts.items():
+                dev.set_option(k, v)
+            cases = list(CYCLE_VIEWS) if not opts else CYCLE_VIEWS[:3]
+            if cyc:
+                cases += [(View(-0.5, -0.5, 0.5, 0.5, 100, 100), m) for m in (9, 10, 24, 25, 26, 40, 41, 42, 56, 57, 58, 72, 73, 105)]
+            for view, mrd in cases:
+                c, b, st = dev.compute_view(view, mrd, kernel=kernel, precision=precision)
+                oc, ob, total = _oracle_view_memo(oracle, view, mrd, precision)
+                assert np.array_equal(c, oc), (view, mrd, kernel, precision, cyc, opts, int((c != oc).sum()))
+                assert np.array_equal(b, ob) and st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum())
+
+
+def test_cycle_detection_smooth(gpu, oracle):
+    """The smooth entry point with the cycle test on (the default): the value of a retired pixel is 0 like any
+    never-escaping pixel's."""
+    view, mrd = View(-0.3, -0.2, 0.5, 0.4, 200, 160), 2500
+    nu, c, _ = gpu.compute_view_smooth(view, mrd, kernel="group")
+    onu, oc = oracle.view_smooth(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd)
+    assert np.array_equal(c, oc)
+    assert np.array_equal(nu == 0.0, oc == 0) and np.allclose(nu, onu, rtol=0, atol=1e-12 * mrd)
+    assert gpu.get_option("cycle_detect") == 1

@@ -205,3 +205,27 @@ def test_contraction_whatif_is_a_different_function(oracle):
     fused = oracle.view_contracted(-0.75, 0.09, 0.02, 0.02, 512, 512, 2000)
     diff = int((strict != fused).sum())
     assert 0 < diff < 0.05 * strict.size
+
+
+def test_cycle_retirement_claim(oracle):
+    """What the GPU kernels' cycle test (MBK_OPT_CYCLE_DETECT) relies on, checked on the CPU model of it
+    (oracle.view_cycle): stopping a pixel as 'never escapes' when its (zr, zi) bit pattern repeats gives exactly
+    the counts of the strict loop (WorkerCUDA.py:39-68) -- on interior-heavy views, for several check periods --
+    while running fewer steps than mrd-1 for pixels of the set."""
+    cases = [(-2.0, -1.5, 3.0, 3.0, 400, 400, 1000), (-0.2, -0.1, 0.2, 0.2, 96, 96, 5000),
+             (-1.1, -0.1, 0.2, 0.2, 96, 96, 3000), (-0.16, 0.70, 0.08, 0.08, 96, 96, 4000),
+             (0.20, -0.05, 0.10, 0.10, 64, 64, 2000), (-0.743648, 0.131820, 1e-5, 1e-5, 64, 64, 3000)]
+    saved = 0
+    for sr, si, rr, ri, w, h, mrd in cases:
+        strict, _, _ = oracle.view(sr, si, rr, ri, w, h, mrd, want_bytes=False)
+        for first, check in ((8, 16), (0, 1), (8, 32), (3, 7)):
+            counts, executed = oracle.view_cycle(sr, si, rr, ri, w, h, mrd, first=first, check=check)
+            assert np.array_equal(counts, strict), (sr, si, mrd, first, check)
+            ref_steps = np.where(strict > 0, strict, mrd - 1)
+            assert (executed <= ref_steps).all() and (executed[strict > 0] == strict[strict > 0]).all()
+            saved += int((ref_steps - executed).sum())
+    assert saved > 0
+    # c = 0 and c = -1: exactly periodic from the start
+    for cr in (0.0, -1.0):
+        counts, executed = oracle.view_cycle(cr, 0.0, 0.0, 0.0, 1, 1, 100000)
+        assert counts[0, 0] == 0 and executed[0, 0] < 100
