@@ -572,11 +572,16 @@ static int launch_reduce(mbk_ctx *ctx, Slot &sl, const int32_t *d_counts, const 
                          uint32_t mrd, hipStream_t stream)
 {
     MBK_HIP(ctx, hipMemsetAsync(sl.d_red, 0, sizeof(ReduceOut), stream));
-    uint64_t blocks = (n + 255) / 256;
+    const bool vec = n >= 1024u && ((uintptr_t)d_counts & 15u) == 0u && ((uintptr_t)d_bytes & 3u) == 0u;
+    uint64_t blocks = ((vec ? n / 4u : n) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(mbk::reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
-                       d_bytes, n, mrd, sl.d_red);
+    if (vec)   // four pixels per lane and trip; the scalar kernel serves unaligned sub-buffers and tiny inputs
+        hipLaunchKernelGGL(mbk::reduce_vec_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
+                           d_bytes, n, mrd, sl.d_red);
+    else
+        hipLaunchKernelGGL(mbk::reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
+                           d_bytes, n, mrd, sl.d_red);
     MBK_HIP(ctx, hipGetLastError());
     MBK_HIP(ctx, hipMemcpyAsync(sl.h_red, sl.d_red, sizeof(ReduceOut), hipMemcpyDeviceToHost, stream));
     return MBK_OK;

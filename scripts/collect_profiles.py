@@ -13,17 +13,21 @@ for f in sorted(glob.glob(os.path.join(src, "*_kernel_stats.csv"))):
     shutil.copy(f, dst)
 for f in sorted(glob.glob(os.path.join(src, "power_*.json"))):
     shutil.copy(f, dst)
-for extra in ("rocminfo.txt", "nproc.txt", "valu_rates.log", "level16.log", "worker_e2e.log", "cfg2_default_pmc_by_kernel.json"):
+for extra in ("rocminfo.txt", "nproc.txt", "valu_rates.log", "level16.log", "worker_e2e.log", "cfg2_default_pmc_by_kernel.json", "soak.log",
+              "pytest_gpu.log"):
     p = os.path.join(src, extra)
     if os.path.exists(p):
-        out = extra.replace("valu_rates.log", "valu_rates_microbench.txt")
+        out = extra.replace("valu_rates.log", "valu_rates_microbench.txt").replace("soak.log", "soak.txt").replace("pytest_gpu.log", "pytest_gpu.txt")
         text = "".join(l for l in open(p, errors="replace") if "amdgpu.ids" not in l)
         open(os.path.join(dst, out), "w").write(text)
 # the per-launch HBM traffic bench.py quotes: WRITE_SIZE / FETCH_SIZE of the dominant cfg2 kernel
 by = os.path.join(src, "cfg2_default_pmc_by_kernel.json")
 if os.path.exists(by):
     d = json.load(open(by))
-    dom = max((k for k in d if k.startswith("tile_asm_kernel")), key=lambda k: d[k].get("SQ_INSTS_VALU", {}).get("mean", 0), default=None)
+    # the strict kernel (cycle test off) is the one the headline is measured on; the cycle-test instantiation
+    # (last template argument true) is in the by-kernel file
+    dom = max((k for k in d if k.startswith("tile_asm_kernel") and not k.rstrip(">").endswith("true")),
+              key=lambda k: d[k].get("SQ_INSTS_VALU", {}).get("mean", 0), default=None)
     if dom:
         out = {"kernel": dom}
         out.update(d[dom])

@@ -584,3 +584,29 @@ def test_cycle_detection_smooth(gpu, oracle):
     assert np.array_equal(c, oc)
     assert np.array_equal(nu == 0.0, oc == 0) and np.allclose(nu, onu, rtol=0, atol=1e-12 * mrd)
     assert gpu.get_option("cycle_detect") == 1
+
+
+def test_stats_reduction_vector_and_scalar_paths(gpu, oracle):
+    """The per-tile statistics (pixel-iterations, never-escaped, all-0 / all-1, RLE runs: what DataChunk.cs:82,87 and
+    DataChunkSerializer.cs:56-100 would find by scanning) come from one reduction kernel with a four-pixels-per-lane
+    form for aligned buffers and a scalar form otherwise: both against numpy, for sizes around the group width,
+    for offsets that break the alignment, and for byte patterns with runs ending on every position of a word."""
+    import torch
+    from oracle.serializer import rle_runs
+    rs = np.random.RandomState(9)
+    big = torch.from_numpy(rs.randint(0, 50, size=(1 << 20) + 64).astype(np.int32)).to("cuda:0")
+    host = big.cpu().numpy()
+    for off in (0, 1, 2, 3, 4, 5):
+        for n in (1, 3, 4, 5, 1023, 1024, 1025, 1027, 4099, (1 << 20) + 3):
+            for mrd in (2, 1000):
+                st = gpu.reduce_counts(big.data_ptr() + 4 * off, n, mrd)
+                ref = host[off:off + n].astype(np.int64)
+                assert st.pixel_iterations == int(np.where(ref > 0, ref, mrd - 1).sum()) and st.never_pixels == int((ref == 0).sum()), (off, n, mrd)
+    # byte statistics go through the view entry points: ragged widths put run boundaries on every byte of a word
+    for w, h, mrd in ((517, 203, 40), (1024, 257, 300), (1031, 129, 9), (64, 16, 100), (4099, 8, 50)):
+        view = View(-2.0, -1.25, 2.5, 2.5, w, h)
+        c, b, st = gpu.compute_view(view, mrd)
+        oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, w, h, mrd)
+        assert np.array_equal(b, ob) and st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum())
+        assert st.rle_runs == len(rle_runs(ob.reshape(-1))[0]), (w, h, mrd)
+        assert st.all_bytes_zero == bool((ob == 0).all()) and st.all_bytes_one == bool((ob == 1).all())
