@@ -24,6 +24,7 @@
 
 using mbk::Axis;
 using mbk::ReduceOut;
+using mbk::ReduceSlot;
 using mbk::TileArgs;
 using mbk::WorkQueues;
 
@@ -53,8 +54,8 @@ struct Slot {
     int32_t *d_counts = nullptr;
     uint8_t *d_bytes = nullptr;
     size_t cap_px = 0;
-    ReduceOut *d_red = nullptr;
-    ReduceOut *h_red = nullptr;  // pinned
+    ReduceSlot *d_red = nullptr;   // mbk::kReduceSlots partial results, folded on the host (reduce_total)
+    ReduceSlot *h_red = nullptr;  // pinned copy of d_red
     bool busy = false;           // submitted, not yet waited for
     bool with_bytes = false;
     uint8_t *lazy_h_bytes = nullptr;  // MBK_LAZY_UNIFORM: the byte copy is decided in mbk_wait
@@ -571,29 +572,52 @@ static int ensure_buffers(mbk_ctx *ctx, Slot &sl, size_t px)
 static int launch_reduce(mbk_ctx *ctx, Slot &sl, const int32_t *d_counts, const uint8_t *d_bytes, uint64_t n,
                          uint32_t mrd, hipStream_t stream)
 {
-    MBK_HIP(ctx, hipMemsetAsync(sl.d_red, 0, sizeof(ReduceOut), stream));
+    MBK_HIP(ctx, hipMemsetAsync(sl.d_red, 0, sizeof(ReduceSlot) * mbk::kReduceSlots, stream));
     const bool vec = n >= 1024u && ((uintptr_t)d_counts & 15u) == 0u && ((uintptr_t)d_bytes & 3u) == 0u;
     uint64_t blocks = ((vec ? n / 4u : n) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
-    if (vec)   // four pixels per lane and trip; the scalar kernel serves unaligned sub-buffers and tiny inputs
-        hipLaunchKernelGGL(mbk::reduce_vec_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
+    // four pixels per lane and trip; the scalar kernel serves unaligned sub-buffers and tiny inputs
+    if (vec && d_counts && d_bytes)
+        hipLaunchKernelGGL((mbk::reduce_vec_kernel<true, true>), dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
+                           d_bytes, n, mrd, sl.d_red);
+    else if (vec && d_counts)
+        hipLaunchKernelGGL((mbk::reduce_vec_kernel<true, false>), dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
+                           d_bytes, n, mrd, sl.d_red);
+    else if (vec && d_bytes)
+        hipLaunchKernelGGL((mbk::reduce_vec_kernel<false, true>), dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
                            d_bytes, n, mrd, sl.d_red);
     else
         hipLaunchKernelGGL(mbk::reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
                            d_bytes, n, mrd, sl.d_red);
     MBK_HIP(ctx, hipGetLastError());
-    MBK_HIP(ctx, hipMemcpyAsync(sl.h_red, sl.d_red, sizeof(ReduceOut), hipMemcpyDeviceToHost, stream));
+    MBK_HIP(ctx, hipMemcpyAsync(sl.h_red, sl.d_red, sizeof(ReduceSlot) * mbk::kReduceSlots, hipMemcpyDeviceToHost, stream));
     return MBK_OK;
+}
+
+// the partial results of a finished reduction (the stream has been synchronised), added up
+static ReduceOut reduce_total(const Slot &sl)
+{
+    ReduceOut t = {};
+    for (uint32_t k = 0; k < mbk::kReduceSlots; ++k) {
+        const ReduceOut &r = sl.h_red[k].r;
+        t.pixel_iterations += r.pixel_iterations;
+        t.never_pixels += r.never_pixels;
+        t.run_starts += r.run_starts;
+        t.any_byte_not_zero |= r.any_byte_not_zero;
+        t.any_byte_not_one |= r.any_byte_not_one;
+    }
+    return t;
 }
 
 static void fill_stats_from_reduce(const Slot &sl, mbk_stats *s, bool have_bytes)
 {
-    s->pixel_iterations = sl.h_red->pixel_iterations;
-    s->never_pixels = sl.h_red->never_pixels;
-    s->all_bytes_zero = have_bytes && sl.h_red->any_byte_not_zero == 0 ? 1u : 0u;
-    s->all_bytes_one = have_bytes && sl.h_red->any_byte_not_one == 0 ? 1u : 0u;
-    s->rle_runs = have_bytes ? sl.h_red->run_starts : 0ull;
+    const ReduceOut t = reduce_total(sl);
+    s->pixel_iterations = t.pixel_iterations;
+    s->never_pixels = t.never_pixels;
+    s->all_bytes_zero = have_bytes && t.any_byte_not_zero == 0 ? 1u : 0u;
+    s->all_bytes_one = have_bytes && t.any_byte_not_one == 0 ? 1u : 0u;
+    s->rle_runs = have_bytes ? t.run_starts : 0ull;
 }
 
 // ------------------------------------- C ABI ---------------------------------------------------
@@ -657,8 +681,8 @@ int mbk_create(int device, mbk_ctx **out)
         MBK_CREATE_HIP(hipEventCreate(&sl.ev_k1));
         MBK_CREATE_HIP(hipEventCreate(&sl.ev_c0));
         MBK_CREATE_HIP(hipEventCreate(&sl.ev_c1));
-        MBK_CREATE_HIP(hipMalloc((void **)&sl.d_red, sizeof(ReduceOut)));
-        MBK_CREATE_HIP(hipHostMalloc((void **)&sl.h_red, sizeof(ReduceOut), hipHostMallocDefault));
+        MBK_CREATE_HIP(hipMalloc((void **)&sl.d_red, sizeof(ReduceSlot) * mbk::kReduceSlots));
+        MBK_CREATE_HIP(hipHostMalloc((void **)&sl.h_red, sizeof(ReduceSlot) * mbk::kReduceSlots, hipHostMallocDefault));
     }
     {
         const void *fns[2][2] = {{(const void *)mbk::tile_light_kernel<double, true, true>, (const void *)mbk::tile_todo_kernel<double>},
@@ -799,7 +823,8 @@ static int wait_slot(mbk_ctx *ctx, Slot &sl, mbk_stats *stats)
     if (sl.lazy_h_bytes) {   // MBK_LAZY_UNIFORM: copy the bytes only if the tile is not all-0 / all-1
         uint8_t *dst = sl.lazy_h_bytes;
         sl.lazy_h_bytes = nullptr;
-        if (sl.h_red->any_byte_not_zero != 0 && sl.h_red->any_byte_not_one != 0) {
+        const ReduceOut t = reduce_total(sl);
+        if (t.any_byte_not_zero != 0 && t.any_byte_not_one != 0) {
             MBK_HIP(ctx, hipEventRecord(sl.ev_c0, sl.stream));
             MBK_HIP(ctx, hipMemcpyAsync(dst, sl.d_bytes, sl.lazy_px, hipMemcpyDeviceToHost, sl.stream));
             MBK_HIP(ctx, hipEventRecord(sl.ev_c1, sl.stream));

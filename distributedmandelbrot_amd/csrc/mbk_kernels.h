@@ -339,6 +339,14 @@ struct ReduceOut {
     unsigned int any_byte_not_zero;
     unsigned int any_byte_not_one;
 };
+// The kernels accumulate into kReduceSlots partial results, each on its own 128-byte line, and the host adds
+// them up: with one result record every wave's atomics went to the same line, and same-address atomics are
+// serialised by the L2 (8 192 waves x 3 atomics: the reduction of a 64 MiB tile took 166 us, 0.4 TB/s, whatever
+// the loads looked like).
+constexpr uint32_t kReduceSlots = 64;
+struct alignas(128) ReduceSlot {
+    ReduceOut r;
+};
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 {
@@ -348,8 +356,9 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 
 __global__ __launch_bounds__(256) void reduce_kernel(const int32_t *__restrict__ counts,
                                                      const uint8_t *__restrict__ bytes,
-                                                     uint64_t n, uint32_t mrd, ReduceOut *out)
+                                                     uint64_t n, uint32_t mrd, ReduceSlot *slots)
 {
+    ReduceOut *out = &slots[blockIdx.x % kReduceSlots].r;
     const unsigned long long cap = mrd > 1u ? (unsigned long long)mrd - 1ull : 0ull;
     unsigned long long iters = 0, never = 0, starts = 0;
     unsigned int nz = 0, no = 0;
@@ -386,42 +395,61 @@ __global__ __launch_bounds__(256) void reduce_kernel(const int32_t *__restrict__
 // byte per lane and load (111 us for a 64 + 16 MiB tile, 0.7 TB/s: three times the kernel time of a light tile).
 // Run starts inside a 4-byte word: x = w ^ (w << 8 | previous byte) has a non-zero byte k where byte k differs
 // from its predecessor; the byte before the word is loaded separately (same cache line as the neighbour's word).
+template <bool kCounts, bool kBytes>
 __global__ __launch_bounds__(256) void reduce_vec_kernel(const int32_t *__restrict__ counts,
                                                          const uint8_t *__restrict__ bytes,
-                                                         uint64_t n, uint32_t mrd, ReduceOut *out)
+                                                         uint64_t n, uint32_t mrd, ReduceSlot *slots)
 {
+    ReduceOut *out = &slots[blockIdx.x % kReduceSlots].r;
     const unsigned long long cap = mrd > 1u ? (unsigned long long)mrd - 1ull : 0ull;
     unsigned long long iters = 0, never = 0, starts = 0;
     unsigned int nz = 0, no = 0;
-    const uint64_t nq = n >> 2;  // whole groups of four pixels
+    const uint64_t nq = n >> 2;  // whole groups of four pixels (>= 1: the host sends n >= 1024 here)
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t q = tid; q < nq; q += stride) {
-        if (counts) {
-            const int4 c = reinterpret_cast<const int4 *>(counts)[q];
-            iters += c.x > 0 ? (unsigned long long)c.x : cap;
-            iters += c.y > 0 ? (unsigned long long)c.y : cap;
-            iters += c.z > 0 ? (unsigned long long)c.z : cap;
-            iters += c.w > 0 ? (unsigned long long)c.w : cap;
-            never += (c.x == 0) + (c.y == 0) + (c.z == 0) + (c.w == 0);
+    constexpr int kUnroll = 4;   // four independent groups per trip, loaded unconditionally (index clamped) so that
+                                 // all loads of a trip are in flight before the first is used
+    for (uint64_t q0 = tid; q0 < nq; q0 += kUnroll * stride) {
+        int4 c[kUnroll];
+        uint32_t w[kUnroll], prev[kUnroll];
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k) {
+            const uint64_t q = q0 + (uint64_t)k * stride, qc = q < nq ? q : nq - 1u;
+            if (kCounts) c[k] = reinterpret_cast<const int4 *>(counts)[qc];
+            if (kBytes) {
+                w[k] = reinterpret_cast<const uint32_t *>(bytes)[qc];
+                prev[k] = bytes[qc ? 4u * qc - 1u : 0u];
+            }
         }
-        if (bytes) {
-            const uint32_t w = reinterpret_cast<const uint32_t *>(bytes)[q];
-            // pixel 0 always starts a run: pretend its predecessor differs
-            const uint32_t prev = q ? (uint32_t)bytes[4u * q - 1u] : (~w & 0xffu);
-            const uint32_t x = w ^ ((w << 8) | prev);
-            starts += ((x & 0xffu) != 0u) + ((x & 0xff00u) != 0u) + ((x & 0xff0000u) != 0u) + ((x & 0xff000000u) != 0u);
-            nz |= (w != 0u);
-            no |= (w != 0x01010101u);
+#pragma unroll
+        for (int k = 0; k < kUnroll; ++k) {
+            const uint64_t q = q0 + (uint64_t)k * stride;
+            const bool in = q < nq;
+            if (kCounts) {
+                const unsigned long long it = (c[k].x > 0 ? (unsigned long long)c[k].x : cap) + (c[k].y > 0 ? (unsigned long long)c[k].y : cap) +
+                                              (c[k].z > 0 ? (unsigned long long)c[k].z : cap) + (c[k].w > 0 ? (unsigned long long)c[k].w : cap);
+                const unsigned int nv = (c[k].x == 0) + (c[k].y == 0) + (c[k].z == 0) + (c[k].w == 0);
+                iters += in ? it : 0ull;
+                never += in ? nv : 0u;
+            }
+            if (kBytes) {
+                // pixel 0 always starts a run: pretend its predecessor differs
+                const uint32_t pb = q ? prev[k] : (~w[k] & 0xffu);
+                const uint32_t x = w[k] ^ ((w[k] << 8) | pb);
+                const unsigned int st = ((x & 0xffu) != 0u) + ((x & 0xff00u) != 0u) + ((x & 0xff0000u) != 0u) + ((x & 0xff000000u) != 0u);
+                starts += in ? st : 0u;
+                nz |= (in && w[k] != 0u);
+                no |= (in && w[k] != 0x01010101u);
+            }
         }
     }
     const uint64_t i = (nq << 2) + tid;  // the last n mod 4 pixels, one lane each
     if (i < n) {
-        if (counts) {
+        if (kCounts) {
             const int32_t c = counts[i];
             iters += c > 0 ? (unsigned long long)c : cap;
             never += c == 0 ? 1ull : 0ull;
         }
-        if (bytes) {
+        if (kBytes) {
             const uint8_t b = bytes[i];
             nz |= (b != 0);
             no |= (b != 1);
