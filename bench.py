@@ -374,31 +374,49 @@ def main():
         iters_per_step, never = st.pixel_iterations, st.never_pixels
         kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
 
-    # second leg (tiles mode, fp64/fp32 count kernels): the same K steps with the library's default cycle test
-    cyc_leg = None
+    # second leg (tiles mode, fp64/fp32 count kernels): the same K steps with the library's default cycle test.
+    # A failure here must not cost the headline: errors are caught (the barriers stay unconditional, so the ranks
+    # stay in step) and reported in config.cycle_leg_error instead of the cycle_detection object.
+    cyc_leg, cyc_err = None, None
     if not fake and not bands_mode and "cycle_detect" not in options and args.kernel in ("default", "group", "scan"):
-        dev.set_option("cycle_detect", 1)
-        run_steps(max(args.warmup, 2))
-        sync()
+        try:
+            dev.set_option("cycle_detect", 1)
+            run_steps(max(args.warmup, 2))
+            sync()
+        except Exception as e:   # noqa: BLE001 -- reported, not swallowed
+            cyc_err = repr(e)
         barrier()
         t1 = time.perf_counter()
-        run_steps(args.steps)
-        sync()
+        try:
+            if cyc_err is None:
+                run_steps(args.steps)
+                sync()
+        except Exception as e:   # noqa: BLE001
+            cyc_err = repr(e)
         barrier()
         cyc_elapsed = time.perf_counter() - t1
-        st2 = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
-        cyc_leg = (cyc_elapsed, st2.pixel_iterations == iters_per_step and st2.never_pixels == never)
-        dev.set_option("cycle_detect", 0)
+        try:
+            if cyc_err is None:
+                st2 = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
+                cyc_leg = (cyc_elapsed, st2.pixel_iterations == iters_per_step and st2.never_pixels == never)
+            dev.set_option("cycle_detect", 0)
+        except Exception as e:   # noqa: BLE001
+            cyc_err, cyc_leg = repr(e), None
 
     bands_once = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_max = float(t.item())
-        if cyc_leg is not None:
-            t = torch.tensor([cyc_leg[0]], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            cyc_leg = (float(t.item()), cyc_leg[1])
+        if not fake and not bands_mode and "cycle_detect" not in options and args.kernel in ("default", "group", "scan"):
+            # every rank takes part (elapsed < 0 marks a rank whose leg failed: then no rank reports the leg)
+            t = torch.tensor([cyc_leg[0] if cyc_leg else -1.0, -(cyc_leg[0] if cyc_leg else -1.0)], dtype=torch.float64,
+                             device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # [max elapsed, -min elapsed]
+            if cyc_leg is not None and -float(t[1].item()) >= 0.0:
+                cyc_leg = (float(t[0].item()), cyc_leg[1])
+            else:
+                cyc_leg = None
         if bands_mode:
             gathered = [None] * world
             dist.all_gather_object(gathered, my_tickets)
@@ -443,6 +461,7 @@ def main():
                "streams_per_gpu": nstreams, "shard": args.shard, "control_backend": backend,
                "clock_ramp_ms": 0.0 if fake or bands_mode else args.ramp_ms,
                "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz,
+               "cycle_leg_error": cyc_err,
                "occupancy_api_wg_per_cu": device_info.get("scan_occupancy")}
         if bands_mode:
             cfg.update({"bands_per_image": len(bands), "band_rows": band_rows, "bands_exactly_once": bands_once,
