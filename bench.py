@@ -140,12 +140,20 @@ def cpu_baseline(name, workload, precision="f64"):
         _, _, total = o.view(sr, si, rng, rng, w, h, mrd, want_counts=False, want_bytes=False, nthreads=cores,
                              precision=precision)
         sample = f"the whole {w}x{h} tile, all rows"
+        best_dt = time.perf_counter() - t0
+        if best_dt < 2.0:   # short run: the first pass also pays for waking the OpenMP team; report the best of
+            for _ in range(2):   # three passes (the baseline at its best, not at its worst)
+                t1 = time.perf_counter()
+                o.view(sr, si, rng, rng, w, h, mrd, want_counts=False, want_bytes=False, nthreads=cores, precision=precision)
+                best_dt = min(best_dt, time.perf_counter() - t1)
+            sample += " (best of 3 passes)"
     else:
         for win in bands:
             total += o.view(sr, si, rng, rng, w, h, mrd, window=win, want_counts=False,
                             want_bytes=False, nthreads=cores, precision=precision)[2]
         sample = f"every {stride}th 8-row band of the {w}x{h} tile ({len(bands) * 8} rows)"
-    dt = time.perf_counter() - t0
+        best_dt = time.perf_counter() - t0
+    dt = best_dt
     rec = {"value": total / dt / 1e9, "unit": "G pixel-iterations/s", "cores": cores, "kind": "port",
            "sample": sample + f", mrd {mrd}, C oracle gcc -O2 -ffp-contract=off, OpenMP dynamic rows",
            "seconds": dt}
@@ -159,9 +167,11 @@ def cpu_baseline(name, workload, precision="f64"):
     rec["single_thread"] = {"value": tot1 / dt1 / 1e9, "seconds": dt1, "sample": f"every 16th 8-row band ({h // 16} rows)"}
     if precision == "f64" and stride == 1 and o.have_avx512():
         # best-effort CPU: the same strict arithmetic 8 pixels at a time in AVX-512 (no fmadd), same threads
-        t0 = time.perf_counter()
-        _, total8 = o.view_avx512(sr, si, rng, rng, w, h, mrd, want_counts=False, nthreads=cores)
-        dt8 = time.perf_counter() - t0
+        dt8 = None
+        for _ in range(3):   # best of three, as above
+            t0 = time.perf_counter()
+            _, total8 = o.view_avx512(sr, si, rng, rng, w, h, mrd, want_counts=False, nthreads=cores)
+            dt8 = min(dt8, time.perf_counter() - t0) if dt8 is not None else time.perf_counter() - t0
         rec["best_effort_avx512"] = {"value": total8 / dt8 / 1e9, "seconds": dt8, "bit_identical_work": total8 == total}
     return rec
 
