@@ -208,6 +208,9 @@ def test_bench_json_contract_single_rank_fake():
     assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["vs_baseline"] is None
     assert rec["unit"] == "G pixel-iterations/s" and rec["dtype"] == "f64" and "workload" in rec["config"]
     assert "model" not in rec["config"]
+    # the headline is the strict leg (every iteration executed); the cycle-test leg needs a GPU and is absent here
+    assert rec["config"]["cycle_test"].startswith("off for value and roofline") and rec["config"]["cycle_leg_error"] is None
+    assert "cycle_detection" not in rec
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert key in rec["roofline"], key
     assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-12
