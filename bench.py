@@ -1,19 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the Mandelbrot tile escape-time path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--kernel default]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--kernel default] [--shard own|queue|bands]
 
-One "step" = one pass of the hot path over one synthetic tile already described in HBM terms: the
+One "step" = one pass of the hot path over one batch of synthetic input already described in HBM terms: the
 kernel generates its coordinates itself and writes int32 escape indices to a resident HBM buffer
-(nothing crosses PCIe inside the timed region).  Workload at every N: BASELINE.json configs[1]
-("cfg2"): 4096x4096 samples of the full set (centre -0.5+0i, span 3.0), max_iter (mrd) = 1000, fp64.
-For N > 1 the driver launches one rank per GPU (torch.distributed.run); tiles are independent, so
-every rank computes its own tile with no data-path collective ("weak" scaling); the only
-communication is the barrier and the max-over-ranks of the elapsed time, on gloo (CPU tensors) -- there
-is no RCCL anywhere (`--control nccl` exists to A/B that choice).  `--shard bands` is the strong-scaling
-form BASELINE cfg3 asks for: ONE view per step, cut into >= 16 row bands per GPU (of >= 128 rows) which the ranks pull
-from a cursor in shared memory (distributedmandelbrot_amd.sharding.SharedCursor; dynamic, because band
-cost varies >100x), two bands in flight per GPU.
+(nothing crosses PCIe inside the timed region).  Workload: BASELINE.json configs[1] ("cfg2"): 4096x4096
+samples of the full set (centre -0.5+0i, span 3.0), max_iter (mrd) = 1000, fp64.
+
+N = 1 (the contract's headline): one cfg2 tile per step, launches back to back on one stream, HIP events
+around every launch (`--shard own`).
+
+N > 1: `python bench.py --gpus N` starts its own N ranks (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment, exactly what `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+sets -- that launcher works too and is detected by WORLD_SIZE).  Tiles are independent, so there is no data-path
+collective and no RCCL anywhere: the only communication is a barrier, the max-over-ranks of the elapsed time and
+a few gathered Python objects, on gloo (`--control nccl` exists to A/B that choice).  Three ways to shard:
+
+  --shard queue (default for N > 1; strong scaling -- the north star's partition: "DataChunk tiles sharded across
+                the GPUs by a plain per-GPU work queue", the shape of Distributer.cs:335-392 where many clients pull
+                from one hand-out loop).  The job of one step is a FIXED set of T = grid x grid DataChunk-sized
+                (4096x4096) tiles covering the workload's view at grid-times finer pitch (default 8 x 8 = 64 tiles:
+                far exterior, boundary and all-interior tiles mixed, cost ratio > 100x).  Every rank pulls ticket
+                numbers from ONE cursor in shared memory (sharding.SharedCursor), ticket t = tile t mod T of step
+                t div T, two tiles in flight per GPU, tickets running on across steps (no barrier between steps).
+                Rank 0 checks that every ticket was taken exactly once (`tiles_exactly_once`) and reports
+                `tiles_per_rank`, the ranks' finish times and `ranks_seen` (host, pid, GPU name, PCI bus id of
+                every rank: there is no RCCL to ask whether N distinct GPUs took part).
+  --shard own   (default for N = 1; weak scaling): every rank computes its own cfg2 tile per step.
+  --shard bands (strong scaling of ONE view, BASELINE cfg3's form): one view per step, cut into >= 16 row bands per
+                GPU (of >= 128 rows) pulled from the same kind of cursor, two bands in flight per GPU.
 
 Before the W warm-up steps the clock is pre-conditioned for --ramp-ms (150 ms) with untimed launches of
 the same workload: an idle MI355X needs 50-100 ms of load to reach its sustained clock, and a 0.6 ms tile
@@ -29,7 +45,9 @@ slots per 8 flops (6 arithmetic ops per step + one add and one compare per 16 st
 fraction cannot exceed 8/12.25 = 0.653; `valu_slot_util` (= issue slots actually spent per
 pixel-iteration over the 39.3 T lane-op/s issue peak at 2.4 GHz) is the "how close to the metal"
 figure.  `traffic` is HBM bytes per launch from separate `rocprofv3 --pmc` passes of this same command
-(committed under profiles/, see `traffic_source`); counters cannot be read from inside the run.
+(committed under profiles/, see `traffic_source`); counters cannot be read from inside the run, so the
+committed summary carries a hash of the kernel sources it was collected on and `traffic` is null when the
+sources in the tree differ from it (a stale profile must not be quoted for a changed kernel).
 `cpu_baseline`: the strict-IEEE C oracle (oracle/, kind "port": the reference has no CPU
 implementation and its numba path cannot run here) on the host cores, rank 0, N = 1 only.
 
@@ -39,6 +57,13 @@ executed.  `value` and `roofline` are therefore measured with the test OFF (ever
 in config.cycle_test); the same K steps with the default ON are timed right after in the same run and
 reported as the extra object `cycle_detection` (reference-equivalent rate, ms per step, speed-up).
 `--opt cycle_detect=1` moves the test into the headline, labelled as such.
+
+Two more extra objects at N = 1, both outside `value` (SURVEY.md 8d "reported beside it"):
+`end_to_end` -- a whole level of the reference's pyramid (level 16, mrd 1024: 256 DataChunk tiles) through the
+host-buffer API, i.e. kernel + quantise + statistics + D2H into pinned memory: tiles/s synchronous, with two tiles
+in flight, and with uniform tiles not copied (what the worker does); kernel median / mean / max, D2H mean;
+`queue_job` -- the N > 1 default job (--shard queue) run on this one GPU, i.e. the same-mode N = 1 point of the
+scaling curve.
 """
 from __future__ import annotations
 
@@ -85,7 +110,7 @@ CPU_SAMPLE_STRIDE = {"cfg4": 256}
 PMC_SUMMARIES = [("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, ~0.3-6 s of GPU time)")
@@ -104,16 +129,70 @@ def parse_args():
                     help="counts (default, the contract's workload): int32 escape indices. both: also the quantised "
                          "uint8 tile the worker sends (what a DataChunk launch writes), for kernel studies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--shard", default="tiles", choices=["tiles", "bands"],
-                    help="tiles (default): every rank computes its own tile per step (weak scaling). bands: ONE "
-                         "view per step, cut into >= 16 row bands per GPU that the ranks pull from a shared-memory "
-                         "cursor (strong scaling; how BASELINE cfg3 shards an image over 8 GPUs)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip the end_to_end and queue_job objects (kernel studies, profiling passes)")
+    ap.add_argument("--shard", default=None, choices=["own", "tiles", "queue", "bands"],
+                    help="own (default for N = 1; 'tiles' is its old name): every rank computes its own tile per step "
+                         "(weak scaling). queue (default for N > 1): one step = a fixed set of grid x grid 4096^2 tiles "
+                         "that the ranks pull from a shared-memory cursor (strong scaling; the per-GPU work queue of the "
+                         "north star). bands: ONE view per step, cut into >= 16 row bands per GPU pulled from the cursor "
+                         "(strong scaling; how BASELINE cfg3 shards an image over 8 GPUs)")
+    ap.add_argument("--grid", type=int, default=8, help="--shard queue: the job is grid x grid tiles (default 8 -> 64 tiles per step)")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for --shard bands (default: height / (16 N), >= 128)")
     ap.add_argument("--streams", type=int, default=None,
-                    help="tiles (or bands) in flight per GPU (default 1 for tiles = the contract's serial steps, 2 for bands)")
+                    help="tiles (or bands) in flight per GPU (default 1 for own = the contract's serial steps, 2 for queue / bands)")
     ap.add_argument("--control", default="gloo", choices=["gloo", "nccl"],
                     help="backend of the barrier / timing reductions for N > 1 (no data-path collective exists)")
-    return ap.parse_args()
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="functional test only: rank r uses GPU r mod (visible GPUs), so that the N > 1 path can be "
+                         "exercised on a box with fewer GPUs than ranks (labelled in config; never a scaling number)")
+    args = ap.parse_args(argv)
+    if args.shard == "tiles":
+        args.shard = "own"
+    return args
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside any launcher: start the N ranks ourselves -- one process per GPU with the
+    environment torch.distributed's env:// rendezvous reads (what torch.distributed.run would set), wait for all
+    of them, and pass rank 0's stdout (the one JSON line) through.  If a rank dies the others are stopped (exact
+    PIDs only) and the exit code is that rank's."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:            # a free rendezvous port
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MBK_BENCH_RUN_ID=f"{os.getpid()}")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+
+    def forward():   # rank 0's JSON line goes to stdout; library chatter that lands on its stdout (gloo) to stderr
+        for line in procs[0].stdout:
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+
+    import threading
+    fwd = threading.Thread(target=forward, daemon=True)
+    fwd.start()
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {procs.index(p)} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
+    fwd.join(timeout=10)
+    return rc
 
 
 def cpu_baseline(name, workload, precision="f64"):
@@ -176,27 +255,107 @@ def cpu_baseline(name, workload, precision="f64"):
     return rec
 
 
+
+def kernel_source_hash():
+    """sha256 over the HIP sources of libmbk_hip.so (what a committed PMC summary was collected on)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "distributedmandelbrot_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".inc")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(workload, kernel):
     """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same command:
     WRITE_SIZE and FETCH_SIZE are in KiB, each collected in its own pass; FETCH_SIZE is doubled as
-    MI355X_MICROARCH.md prescribes for gfx950.  (None, None) for un-profiled combinations."""
+    MI355X_MICROARCH.md prescribes for gfx950.  (None, why) for un-profiled combinations and for a summary
+    whose `source_sha256` is not the hash of the kernel sources in this tree (stale profile)."""
     if workload != "cfg2" or kernel not in ("default", "scan", "group"):
         return None, None
+    have = kernel_source_hash()
+    why = None
     for rnd, fname in PMC_SUMMARIES:
         path = os.path.join(ROOT, "profiles", rnd, fname)
         try:
             with open(path) as f:
                 pmc = json.load(f)
+            if pmc.get("source_sha256") != have:
+                why = why or (f"profiles/{rnd}/{fname} was collected on other kernel sources (source_sha256 "
+                              f"{str(pmc.get('source_sha256'))[:12]} != {have[:12]} in this tree): not quoted")
+                continue
             nbytes = int(pmc["WRITE_SIZE"]["mean"] * 1024 + 2 * pmc["FETCH_SIZE"]["mean"] * 1024)
-            return nbytes, f"profiles/{rnd}/{fname}: separate rocprofv3 --pmc passes of this command, not counters of this run"
+            return nbytes, f"profiles/{rnd}/{fname}: separate rocprofv3 --pmc passes of this command on these kernel sources, not counters of this run"
         except Exception:
             continue
-    return None, None
+    return None, why
+
+
+def end_to_end(dev, level=16, mrd=1024):
+    """the tile rate INCLUDING quantise + statistics + D2H, reported beside the headline.  A whole
+    level of the reference's pyramid (level n = n x n DataChunk tiles of [-2,2]^2, Distributer.cs:335-353 hands out
+    every one of them) through the host-buffer API into pinned memory, library defaults (cycle test on):
+    synchronous (WorkerCUDA.py:87-98's shape), two tiles in flight, and two in flight with uniform tiles not
+    copied off the GPU (MBK_LAZY_UNIFORM: what worker.run_pipelined does)."""
+    import numpy as np
+    tiles = [(ir, ii) for ir in range(level) for ii in range(level)]
+    n = len(tiles)
+    pins = [dev.pinned_empty((16777216,), np.uint8) for _ in range(2)]
+    dev.datachunk(level, mrd, 0, 0, out_bytes=pins[0])   # warm-up
+    ks, ds, never, imm, iters = [], [], 0, 0, 0
+    t0 = time.perf_counter()
+    for ir, ii in tiles:
+        _, _, st = dev.datachunk(level, mrd, ir, ii, out_bytes=pins[0])
+        ks.append(st.kernel_ms)
+        ds.append(st.d2h_ms)
+        never += st.all_bytes_zero
+        imm += st.all_bytes_one
+        iters += st.pixel_iterations
+    t_sync = time.perf_counter() - t0
+
+    def two_slots(lazy):
+        t1 = time.perf_counter()
+        dev.submit_datachunk(0, level, mrd, *tiles[0], pins[0], lazy_uniform=lazy)
+        for i in range(1, n + 1):
+            if i < n:
+                dev.submit_datachunk(i % 2, level, mrd, *tiles[i], pins[i % 2], lazy_uniform=lazy)
+            dev.wait((i - 1) % 2)
+        return time.perf_counter() - t1
+
+    t_two = two_slots(False)
+    t_lazy = two_slots(True)
+    ks_sorted = sorted(ks)
+    return {"what": f"level {level} of the reference's pyramid, mrd {mrd}: {n} DataChunk tiles (4096^2) through the host-buffer "
+                    "API on one context -- kernel + quantise + statistics + D2H of the 16 MiB byte tile into pinned memory, "
+                    "library defaults (cycle test on); not part of `value`",
+            "tiles": n, "uniform_never_tiles": int(never), "uniform_immediate_tiles": int(imm),
+            "tiles_per_s_synchronous": n / t_sync, "tiles_per_s_two_in_flight": n / t_two,
+            "tiles_per_s_two_in_flight_lazy_uniform": n / t_lazy,
+            "G_pixel_iterations_per_s_wall_synchronous": iters / t_sync / 1e9,
+            "kernel_ms_median": ks_sorted[n // 2], "kernel_ms_mean": sum(ks) / n, "kernel_ms_max": ks_sorted[-1],
+            "d2h_ms_mean": sum(ds) / n}
 
 
 def main():
     args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit(self_launch(args))     # start our own N ranks; each comes back here with WORLD_SIZE = N
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    fake = os.environ.get("MBK_BENCH_FAKE") == "1"   # CPU-only test hook for the N>1 control path
+    if fake and os.environ.get("MBK_BENCH_FAKE_DIE_RANK") == str(rank):   # test hook: a rank that dies at start-up
+        raise SystemExit(3)
+    if args.shard is None:
+        args.shard = "queue" if world > 1 else "own"
+    own_mode, queue_mode, bands_mode = args.shard == "own", args.shard == "queue", args.shard == "bands"
     d_steps, d_warm = DEFAULT_STEPS.get(args.workload, (20, 3))
+    if queue_mode:   # a step is grid^2 tiles, not one
+        d_steps, d_warm = max(2, d_steps * 4 // (args.grid * args.grid)), 1
     if args.steps is None:
         args.steps = d_steps
     if args.warmup is None:
@@ -204,20 +363,12 @@ def main():
     if args.precision is None:
         args.precision = DEFAULT_PRECISION.get(args.workload, "f64")
     smooth = args.workload in SMOOTH_WORKLOADS
-    bands_mode = args.shard == "bands"
     if args.streams is None:
-        args.streams = 2 if bands_mode else 1
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    fake = os.environ.get("MBK_BENCH_FAKE") == "1"   # CPU-only test hook for the N>1 control path
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    if smooth and (bands_mode or args.precision != "f64"):
-        raise SystemExit("cfg5 (smooth colouring) runs with --shard tiles in fp64")
+        args.streams = 1 if own_mode else 2
+    if smooth and (not own_mode or args.precision != "f64"):
+        raise SystemExit("cfg5 (smooth colouring) runs with --shard own in fp64")
+    if args.grid < 1 or args.grid > 15:
+        raise SystemExit("--grid must be in 1..15 (the grid view has grid x 4096 < 2^16 columns)")
     options = {}
     for item in args.opt:
         k, _, v = item.partition("=")
@@ -231,6 +382,7 @@ def main():
     npix = width * height
 
     backend = None
+    gpu_index = local_rank
     if world > 1:
         if fake or args.control == "gloo":
             backend = "gloo"     # barrier + two scalar reductions on CPU tensors: nothing here needs RCCL
@@ -239,10 +391,19 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
             backend = "nccl"
+    if not fake and args.oversubscribe:
+        gpu_index = local_rank % max(1, torch.cuda.device_count())
 
     def barrier():
         if world > 1:
             dist.barrier()
+
+    def gather(obj):
+        if world == 1:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
 
     nstreams = max(1, args.streams)
     # >= 16 bands per GPU, but no band under 128 rows: a band costs ~70 us of host work (cursor lock, two kernel
@@ -252,25 +413,36 @@ def main():
     band_rows = max(8, (band_rows // 8) * 8)
     from distributedmandelbrot_amd.sharding import SharedCursor, make_bands
     bands = make_bands(height, band_rows) if bands_mode else None
+    ntiles = args.grid * args.grid if queue_mode else 0
+    units = bands if bands_mode else list(range(ntiles))     # what a ticket maps to (ticket mod len(units))
     cursor = None
-    if bands_mode:
-        cname = f"{os.environ.get('MASTER_PORT', 'solo')}_{os.environ.get('TORCHELASTIC_RUN_ID', os.getppid())}"
-        if rank == 0:
-            cursor = SharedCursor(cname, create=True)
-        barrier()
-        if rank != 0:
-            cursor = SharedCursor(cname, create=False)
 
+    def open_cursor(tag):
+        cname = (f"{tag}_{os.environ.get('MASTER_PORT', 'solo')}_"
+                 f"{os.environ.get('MBK_BENCH_RUN_ID', os.environ.get('TORCHELASTIC_RUN_ID', os.getppid() if world > 1 else os.getpid()))}")
+        c = SharedCursor(cname, create=True) if rank == 0 else None
+        barrier()
+        return c if rank == 0 else SharedCursor(cname, create=False)
+
+    if bands_mode or queue_mode:
+        cursor = open_cursor("b" if bands_mode else "q")
+
+    dev = None
+    me = {"rank": rank, "local_rank": local_rank, "host": os.uname().nodename, "pid": os.getpid()}
     if fake:
-        dev = None
         device_info = {"name": "fake", "compute_units": 256, "clock_mhz": 2400}
+        me.update(gpu_index=gpu_index, device="fake", pci_bus_id=None)
         streams = [None] * nstreams
 
-        def launch_tile(i):
+        def launch_own(i):
             time.sleep(0.001)
 
-        def launch_band(i, bnd):
-            time.sleep(0.0002 * (1 + bnd.index % 3))
+        def launch_unit(i, u):
+            k = u.index if bands_mode else u
+            time.sleep(0.0002 * (1 + k % 3))
+
+        def unit_stats(u):          # (pixel-iterations, never-escaped pixels) of a queue tile
+            return 10 ** 7 * (1 + u % 3), u % 3
 
         def sync():
             pass
@@ -279,8 +451,8 @@ def main():
             pass
     else:
         from distributedmandelbrot_amd import MandelbrotDevice, View
-        torch.cuda.set_device(local_rank)
-        dev = MandelbrotDevice(local_rank)   # raises loudly without the HIP library / a gfx950 GPU
+        torch.cuda.set_device(gpu_index)
+        dev = MandelbrotDevice(gpu_index)   # raises loudly without the HIP library / a gfx950 GPU
         # The headline is measured with the cycle test OFF: every iteration the reference would run is executed, so
         # `value` and the roofline describe the loop itself.  The library's default (ON: bit-identical counts, exactly
         # periodic orbits retired early) is timed in the same run as the extra object "cycle_detection".
@@ -290,16 +462,20 @@ def main():
             dev.set_option(k, v)
         device_info = dev.info()
         device_info["scan_occupancy"] = dev.scan_occupancy()
+        me.update(gpu_index=gpu_index, device=device_info.get("name"), pci_bus_id=dev.pci_bus_id())
         view = View(sr, si, rng, rng, width, height)
-        nbuf = 1 if bands_mode else nstreams
-        d_counts_all = [torch.empty(npix, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(nbuf)]
-        d_smooth_all = [torch.empty(npix, dtype=torch.float64, device=f"cuda:{local_rank}") for _ in range(nbuf)] if smooth else None
-        d_bytes_all = [torch.empty(npix, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(nbuf)] if args.outputs == "both" else None
+        # --shard queue: grid x grid tiles of width x height samples = windows of ONE view of the same region at
+        # grid-times finer pitch (np.linspace over the whole region, like every view of this library)
+        qview = View(sr, si, rng, rng, width * args.grid, height * args.grid)
+        nbuf = nstreams if (own_mode or queue_mode) else 1
+        d_counts_all = [torch.empty(npix, dtype=torch.int32, device=f"cuda:{gpu_index}") for _ in range(nbuf)]
+        d_smooth_all = [torch.empty(npix, dtype=torch.float64, device=f"cuda:{gpu_index}") for _ in range(nbuf)] if smooth else None
+        d_bytes_all = [torch.empty(npix, dtype=torch.uint8, device=f"cuda:{gpu_index}") for _ in range(nbuf)] if args.outputs == "both" else None
         streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
         slot_events = [torch.cuda.Event() for _ in range(nstreams)]
         slot_busy = [False] * nstreams
 
-        def launch_tile(i):
+        def launch_own(i):
             if smooth:
                 dev.launch_view_smooth(view, mrd, d_smooth=d_smooth_all[i].data_ptr(), d_counts=d_counts_all[i].data_ptr(),
                                        stream=streams[i].cuda_stream, kernel=args.kernel)
@@ -308,14 +484,27 @@ def main():
                                 d_bytes=d_bytes_all[i].data_ptr() if d_bytes_all else 0,
                                 kernel=args.kernel, precision=args.precision)
 
-        def launch_band(i, bnd):   # a row band of the shared view, written at its place in this rank's image
-            dev.launch_view(view, mrd, window=(0, bnd.row0, width, bnd.nrows),
-                            d_counts=d_counts_all[0].data_ptr() + 4 * bnd.row0 * width,
-                            stream=streams[i].cuda_stream, kernel=args.kernel, precision=args.precision)
+        def launch_unit(i, u):
+            if bands_mode:   # a row band of the shared view, written at its place in this rank's image
+                dev.launch_view(view, mrd, window=(0, u.row0, width, u.nrows),
+                                d_counts=d_counts_all[0].data_ptr() + 4 * u.row0 * width,
+                                stream=streams[i].cuda_stream, kernel=args.kernel, precision=args.precision)
+            else:            # tile u of the grid, into this slot's own tile buffer
+                tr, ti = u % args.grid, u // args.grid
+                dev.launch_view(qview, mrd, window=(tr * width, ti * height, width, height),
+                                d_counts=d_counts_all[i].data_ptr(), stream=streams[i].cuda_stream,
+                                d_bytes=d_bytes_all[i].data_ptr() if d_bytes_all else 0,
+                                kernel=args.kernel, precision=args.precision)
             slot_events[i].record(streams[i])
             slot_busy[i] = True
 
-        def slot_wait(i):          # back-pressure: one band in flight per slot, or a rank would drain the cursor
+        def unit_stats(u):
+            launch_unit(0, u)
+            slot_wait(0)
+            st = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
+            return st.pixel_iterations, st.never_pixels
+
+        def slot_wait(i):          # back-pressure: one unit in flight per slot, or a rank would drain the cursor
             if slot_busy[i]:
                 slot_events[i].synchronize()
                 slot_busy[i] = False
@@ -327,21 +516,21 @@ def main():
     my_tickets = []
 
     def run_steps(nsteps, events=None):
-        """tiles: nsteps launches round-robin over the streams.  bands: pull tickets until nsteps images are done."""
-        if not bands_mode:
+        """own: nsteps launches round-robin over the streams.  queue / bands: pull tickets until nsteps steps are done."""
+        if own_mode:
             for _ in range(nsteps):
                 i = turn[0] % nstreams
                 turn[0] += 1
                 if events is not None and not fake:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(streams[i])
-                    launch_tile(i)
+                    launch_own(i)
                     e1.record(streams[i])
                     events.append((e0, e1))
                 else:
-                    launch_tile(i)
+                    launch_own(i)
             return
-        limit = nsteps * len(bands)
+        limit = nsteps * len(units)
         while True:
             i = turn[0] % nstreams
             slot_wait(i)
@@ -351,17 +540,40 @@ def main():
             turn[0] += 1
             if events is not None:
                 my_tickets.append(t)
-            launch_band(i, bands[t % len(bands)])
+            launch_unit(i, units[t % len(units)])
 
-    if not fake and args.ramp_ms > 0 and not bands_mode:   # clock pre-conditioning (untimed, see --ramp-ms)
+    def census():
+        """--shard queue, untimed: one pass over the tile set through the same cursor; every rank measures the
+        pixel-iterations of the tiles it drew from the tiles' own output, and the per-tile figures are gathered:
+        the work of a step is then known exactly without touching the timed region."""
+        mine = {}
+        while True:
+            t = cursor.next()
+            if t >= ntiles:
+                break
+            mine[t] = unit_stats(t)
+        per_tile = {}
+        for g in gather(mine):
+            per_tile.update(g)
+        assert sorted(per_tile) == list(range(ntiles)), "census: a tile was not measured"
+        return per_tile
+
+    per_tile = None
+    if queue_mode:
+        per_tile = census()
+        barrier()
+        if rank == 0:
+            cursor.reset(0)
+        barrier()
+    if not fake and args.ramp_ms > 0 and own_mode:   # clock pre-conditioning (untimed, see --ramp-ms)
         t_ramp = time.perf_counter()
         while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-            launch_tile(0)
+            launch_own(0)
             sync()
-    run_steps(args.warmup if not bands_mode else max(args.warmup, 1))
+    run_steps(args.warmup if own_mode else max(args.warmup, 1))
     sync()
     barrier()
-    if bands_mode:
+    if not own_mode:
         if rank == 0:
             cursor.reset(0)
         barrier()
@@ -369,26 +581,32 @@ def main():
     t0 = time.perf_counter()
     run_steps(args.steps, events)
     sync()
+    my_finish = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
 
     never = 0
-    if fake:
+    if queue_mode:
+        iters_per_step = sum(v[0] for v in per_tile.values())
+        never = sum(v[1] for v in per_tile.values())
+        kernel_ms = [elapsed / args.steps * 1e3]
+    elif fake:
         iters_per_step = 10 ** 9
         kernel_ms = [elapsed / args.steps * 1e3] * args.steps
     else:
         if bands_mode:      # work per step = the whole image, measured once (untimed) on every rank's own GPU
-            launch_tile(0)
+            launch_own(0)
             sync()
         st = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
         iters_per_step, never = st.pixel_iterations, st.never_pixels
         kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
 
-    # second leg (tiles mode, fp64/fp32 count kernels): the same K steps with the library's default cycle test.
+    # second leg (own mode, fp64/fp32 count kernels): the same K steps with the library's default cycle test.
     # A failure here must not cost the headline: errors are caught (the barriers stay unconditional, so the ranks
     # stay in step) and reported in config.cycle_leg_error instead of the cycle_detection object.
     cyc_leg, cyc_err = None, None
-    if not fake and not bands_mode and "cycle_detect" not in options and args.kernel in ("default", "group", "scan"):
+    second_leg = not fake and own_mode and "cycle_detect" not in options and args.kernel in ("default", "group", "scan")
+    if second_leg:
         try:
             dev.set_option("cycle_detect", 1)
             run_steps(max(args.warmup, 2))
@@ -413,69 +631,87 @@ def main():
         except Exception as e:   # noqa: BLE001
             cyc_err, cyc_leg = repr(e), None
 
-    bands_once = None
+    once = None
+    per_rank_units = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else f"cuda:{gpu_index}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_max = float(t.item())
-        if not fake and not bands_mode and "cycle_detect" not in options and args.kernel in ("default", "group", "scan"):
+        if second_leg:
             # every rank takes part (elapsed < 0 marks a rank whose leg failed: then no rank reports the leg)
             t = torch.tensor([cyc_leg[0] if cyc_leg else -1.0, -(cyc_leg[0] if cyc_leg else -1.0)], dtype=torch.float64,
-                             device="cpu" if backend == "gloo" else f"cuda:{local_rank}")
+                             device="cpu" if backend == "gloo" else f"cuda:{gpu_index}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # [max elapsed, -min elapsed]
             if cyc_leg is not None and -float(t[1].item()) >= 0.0:
                 cyc_leg = (float(t[0].item()), cyc_leg[1])
             else:
                 cyc_leg = None
-        if bands_mode:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, my_tickets)
-            allt = sorted(x for g in gathered for x in g)
-            bands_once = allt == list(range(args.steps * len(bands)))
-            per_rank_bands = [len(g) for g in gathered]
     else:
         elapsed_max = elapsed
-        if bands_mode:
-            bands_once = sorted(my_tickets) == list(range(args.steps * len(bands)))
-            per_rank_bands = [len(my_tickets)]
-    # weak scaling: every rank did the same tile; strong scaling: the ranks shared one image per step
-    iters_all = float(iters_per_step) * (1 if bands_mode else world)
+    ranks_seen = gather(me)
+    finish_ms = [round(x * 1e3, 3) for x in gather(my_finish)]
+    if not own_mode:
+        gathered = gather(my_tickets)
+        allt = sorted(x for g in gathered for x in g)
+        once = allt == list(range(args.steps * len(units)))
+        per_rank_units = [len(g) for g in gathered]
+    # weak scaling: every rank did the same tile; strong scaling: the ranks shared the work of every step
+    iters_all = float(iters_per_step) * (world if own_mode else 1)
 
     if rank == 0:
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-        if bands_mode:      # per-GPU average time per image, idle time included
+        if not own_mode:      # per-GPU average time per step, idle time included
             avg_kernel_s = elapsed_max / args.steps
         cus, mhz = device_info["compute_units"], device_info["clock_mhz"]
         lanes_per_clk = 16 if args.precision == "f64" else 32  # per SIMD: fp64 16, fp32 32 (SIMD-32)
         peak_lane_ops = cus * 4 * lanes_per_clk * mhz * 1e6    # VALU lane-ops/s of that type
         peak_tflops = peak_lane_ops * 2 / 1e12                 # FMA = 2 flop -> 78.6 (fp64) / 157.3 (fp32)
-        per_gpu_iters = iters_per_step / (world if bands_mode else 1)
+        per_gpu_iters = iters_per_step / (1 if own_mode else world)
         achieved_tflops = FLOPS_PER_PIXEL_ITER * per_gpu_iters / avg_kernel_s / 1e12
         slots = VALU_SLOTS_PER_PIXEL_ITER.get(args.kernel, 8.0)
         if args.kernel in ("default", "scan", "group") and options.get("group_steps", 16) != 16:
             slots = 6.25 if options["group_steps"] == 8 else 6.5
         if options.get("cycle_detect", 0) and args.kernel in ("default", "scan", "group") and options.get("group_steps", 16) != 4:
             slots += 0.125     # two bitwise state compares per 16 steps
-        out_bytes = npix * (12 if smooth else 4)
-        traffic, traffic_source = pmc_traffic(args.workload, args.kernel) if args.precision == "f64" and not options else (None, None)
+        launches_per_step = ntiles if queue_mode else 1
+        out_bytes = npix * (12 if smooth else 4) * launches_per_step // (1 if own_mode else world)
+        traffic, traffic_source = pmc_traffic(args.workload, args.kernel) if args.precision == "f64" and not options and own_mode else (None, None)
         metric = "G pixel-iterations/s on 4096^2 tile, max_iter=1000 fp64"
-        cfg = {"workload": f"{args.workload}: {desc}; " + (
-                   f"one image per step cut into {len(bands)} row bands of {band_rows} rows pulled from a shared cursor"
-                   if bands_mode else "one tile per GPU per step") + ", int32 counts written to resident HBM",
+        if own_mode:
+            how = "one tile per GPU per step"
+        elif queue_mode:
+            how = (f"one step = {ntiles} tiles of {width}x{height} ({args.grid}x{args.grid} grid over the same region at "
+                   f"{args.grid}x finer pitch), pulled by all ranks from one shared cursor, {nstreams} in flight per GPU")
+        else:
+            how = f"one image per step cut into {len(bands)} row bands of {band_rows} rows pulled from a shared cursor"
+        cfg = {"workload": f"{args.workload}: {desc}; {how}, int32 counts written to resident HBM",
                "kernel": args.kernel, "options": options, "outputs": args.outputs,
                "cycle_test": ("on (--opt)" if options.get("cycle_detect", 0) else
                               "off for value and roofline: every iteration the reference runs is executed" +
                               ("; the library default (on) is timed in this run: see cycle_detection" if cyc_leg else "")),
-               "pixels_per_step": npix * (1 if bands_mode else world), "pixel_iterations_per_step_per_gpu": per_gpu_iters,
-               "never_escaped_pixels": never, "parallelism": f"{world} independent work queue(s), no collective",
+               "pixels_per_step": npix * (world if own_mode else launches_per_step),
+               "pixel_iterations_per_step_per_gpu": per_gpu_iters,
+               "never_escaped_pixels": never, "parallelism": f"{world} independent work queue(s), no collective"
+               if own_mode else f"{world} rank(s) pulling from one shared cursor, no collective",
                "streams_per_gpu": nstreams, "shard": args.shard, "control_backend": backend,
-               "clock_ramp_ms": 0.0 if fake or bands_mode else args.ramp_ms,
+               "clock_ramp_ms": args.ramp_ms if (own_mode and not fake) else 0.0,
                "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz,
                "cycle_leg_error": cyc_err,
-               "occupancy_api_wg_per_cu": device_info.get("scan_occupancy")}
+               "occupancy_api_wg_per_cu": device_info.get("scan_occupancy"),
+               "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                           ("bench.py self-launch" if "MBK_BENCH_RUN_ID" in os.environ else "single process"),
+               "oversubscribed": bool(args.oversubscribe),
+               "ranks_seen": ranks_seen,
+               "distinct_gpus": len({(r["host"], r["pci_bus_id"], r["gpu_index"]) for r in ranks_seen}),
+               "rank_finish_ms": finish_ms}
         if bands_mode:
-            cfg.update({"bands_per_image": len(bands), "band_rows": band_rows, "bands_exactly_once": bands_once,
-                        "bands_per_rank": per_rank_bands})
+            cfg.update({"bands_per_image": len(bands), "band_rows": band_rows, "bands_exactly_once": once,
+                        "bands_per_rank": per_rank_units})
+        if queue_mode:
+            tile_iters = [per_tile[k][0] for k in range(ntiles)]
+            cfg.update({"tiles_per_step": ntiles, "grid": args.grid, "tiles_exactly_once": once,
+                        "tiles_per_rank": per_rank_units,
+                        "tile_pixel_iterations_min_max": [min(tile_iters), max(tile_iters)]})
         rec = {
             "metric": metric,
             "value": iters_all * args.steps / elapsed_max / 1e9,
@@ -485,7 +721,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if bands_mode else "weak",
+            "scaling": "weak" if own_mode else "strong",
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic (coordinates generated in-kernel from the view origin and stride; no RNG)",
@@ -498,9 +734,10 @@ def main():
                 "frac": achieved_tflops / peak_tflops,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                "basis": "whole-job wall time per image per GPU (idle time included)" if bands_mode
-                         else "HIP events around each launch on its stream",
+                "basis": "HIP events around each launch on its stream" if own_mode
+                         else "whole-job wall time per step per GPU (idle time included)",
                 "kernel_ms_avg": avg_kernel_s * 1e3,
+                "kernel_ms_median": sorted(kernel_ms)[len(kernel_ms) // 2] if own_mode else avg_kernel_s * 1e3,
                 "kernel_ms_min": min(kernel_ms),
                 "flops_per_pixel_iteration": FLOPS_PER_PIXEL_ITER,
                 "valu_slots_per_pixel_iteration": slots,
@@ -508,7 +745,7 @@ def main():
                 # reference's count says, so the executed-issue figures cannot be derived from the output
                 "parity_ceiling_frac": None if options.get("cycle_detect", 0) else FLOPS_PER_PIXEL_ITER / (2.0 * slots),
                 "valu_slot_util": None if options.get("cycle_detect", 0) else slots * per_gpu_iters / avg_kernel_s / peak_lane_ops,
-                "algorithmic_hbm_bytes_per_launch": out_bytes,
+                "algorithmic_hbm_bytes_per_launch": npix * (12 if smooth else 4),
                 "hbm_GBps": out_bytes / avg_kernel_s / 1e9,
             },
         }
@@ -523,6 +760,16 @@ def main():
                 "speedup_vs_strict": elapsed_max / cyc_leg[0],
                 "same_pixel_iterations_and_never_count": bool(cyc_leg[1]),
             }
+        if world == 1 and own_mode and not fake and not args.no_extras and args.workload == "cfg2" and not smooth:
+            # beside the headline (never in `value`): the end-to-end tile rate, and the N > 1 default job on this GPU
+            try:
+                dev.set_option("cycle_detect", 1)
+                rec["end_to_end"] = end_to_end(dev)
+            except Exception as e:   # noqa: BLE001 -- reported, must not cost the headline
+                rec["end_to_end"] = {"error": repr(e)}
+            finally:
+                dev.set_option("cycle_detect", options.get("cycle_detect", 0))
+            rec["queue_job"] = queue_job_single(args, rec["value"])
         if world == 1 and not args.no_cpu_baseline and not fake:
             rec["cpu_baseline"] = cpu_baseline(args.workload, workload, args.precision)
         elif world == 1 and fake:
@@ -536,6 +783,27 @@ def main():
         dist.destroy_process_group()
     if dev is not None:
         dev.close()
+
+
+def queue_job_single(args, headline_value):
+    """The N > 1 default job (--shard queue) on ONE GPU, in a process of its own: the same-mode N = 1 point of the
+    scaling curve (value(N) / (N x this) is the efficiency of the queue; `value` of the headline is a single tile
+    per step, whose rate differs by the tiles' pitch)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--shard", "queue", "--no-cpu-baseline", "--no-extras",
+           "--workload", args.workload, "--kernel", args.kernel, "--grid", str(args.grid), "--steps", "3", "--warmup", "1"]
+    for item in args.opt:
+        cmd += ["--opt", item]
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        return {"what": "the default N > 1 job (--shard queue) on this one GPU: " + rec["config"]["workload"],
+                "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+                "tiles_per_step": rec["config"]["tiles_per_step"], "tiles_exactly_once": rec["config"]["tiles_exactly_once"],
+                "ratio_to_headline_value": rec["value"] / headline_value if headline_value else None}
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)}
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MB
 # enum mbk_option (include/mbk.h), in order
 OPTIONS = {name: i for i, name in enumerate(
     ["order", "waves_per_wg", "group_steps", "exact_steps", "probe_steps", "scan_waves", "scan_xcd_map", "scan_col_period", "heavy_share",
-     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect"])}
+     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid"])}
 MBK_PRECISION_F32 = 0x1000
 MBK_LAZY_UNIFORM = 0x2000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
@@ -37,7 +37,7 @@ MBK_CODEC_RAW = 0x00
 MBK_CODEC_RLE = 0x01
 MBK_CHUNK_DEFINITION = 4096
 MBK_CHUNK_BYTES = 4096 * 4096
-MBK_ABI_VERSION = 2
+MBK_ABI_VERSION = 3
 
 
 class mbk_view(C.Structure):
@@ -69,6 +69,7 @@ SIGNATURES = {
     "mbk_destroy": (None, [C.c_void_p]),
     "mbk_last_error": (C.c_char_p, [C.c_void_p]),
     "mbk_get_device_info": (C.c_int, [C.c_void_p, C.POINTER(mbk_device_info)]),
+    "mbk_device_pci_bus_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "mbk_host_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mbk_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mbk_datachunk_geometry": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32,

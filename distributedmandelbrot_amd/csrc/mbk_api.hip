@@ -41,8 +41,11 @@ struct StreamScratch {
     uint32_t *d_entries = nullptr;   // kernel "scan": the 64 todo lists (block ids)
     size_t scan_cap_blocks = 0;      // their capacity, in ids
     unsigned scan_turn = 0;
+    bool cursors_dirty = false;      // a scan launch failed after its cursor sets were assigned: clear both next time
     uint32_t *h_hint = nullptr;   // pinned, written by the kernels of the last launch on this stream:
                                   // [0] longest deferred list (scan pass 2), [1] share of heavy blocks x 65536
+    ReduceSlot *d_red = nullptr;  // mbk_reduce_counts on this (caller) stream: its own partial results, so that a
+    ReduceSlot *h_red = nullptr;  // reduction on a caller stream never shares a buffer with a tile in flight on a slot
 };
 static const size_t kMaxStreamScratch = 64;
 
@@ -195,6 +198,8 @@ static void free_scratch(StreamScratch &sc)
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
     if (sc.h_hint) (void)hipHostFree(sc.h_hint);
+    if (sc.d_red) (void)hipFree(sc.d_red);
+    if (sc.h_red) (void)hipHostFree(sc.h_red);
     sc = StreamScratch();
 }
 
@@ -256,14 +261,15 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             }
             sc->d_order = nullptr;
             sc->order_cap = 0;
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_order, ((size_t)grid.x + 2u) * sizeof(uint32_t)));
+            // list | 3 counters | middle-class list (classify_blocks_kernel)
+            MBK_HIP(ctx, hipMalloc((void **)&sc->d_order, (2u * (size_t)grid.x + 3u) * sizeof(uint32_t)));
             sc->order_cap = grid.x;
         }
         uint32_t *ord = sc->d_order;
         uint32_t *cursors = ord + grid.x;   // right behind the list: the tile kernel finds them at order[gridDim.x]
-        MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 2 * sizeof(uint32_t), stream));
+        MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, stream, a,
-                           grid.x, 8u * wpw, (int32_t)probe_steps, ord, cursors);
+                           grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
         a.order = ord;
         a.heavy_hint = sc->h_hint + 1;
     }
@@ -412,12 +418,15 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     StreamScratch *sc = nullptr;
     int rc = get_scratch(ctx, stream, &sc);
     if (rc != MBK_OK) return rc;
-    if (!sc->d_cursors) {
-        MBK_HIP(ctx, hipMalloc((void **)&sc->d_cursors, 2 * sizeof(mbk::ScanCursors)));
+    if (!sc->d_cursors || sc->cursors_dirty) {
+        if (!sc->d_cursors) MBK_HIP(ctx, hipMalloc((void **)&sc->d_cursors, 2 * sizeof(mbk::ScanCursors)));
         // once per stream, ON that stream: hipMemset on the null stream does not order against a
-        // non-blocking stream (the first launch on a new stream raced with it and lost listed blocks)
+        // non-blocking stream (the first launch on a new stream raced with it and lost listed blocks).
+        // Also after a failed launch: pass 1 of launch L is what clears the set of launch L+1, so a launch that
+        // failed after taking its sets would leave the next one appending behind stale tails.
         MBK_HIP(ctx, hipMemsetAsync(sc->d_cursors, 0, 2 * sizeof(mbk::ScanCursors), stream));
         sc->scan_turn = 0;
+        sc->cursors_dirty = false;
     }
     const size_t need = (size_t)qcap * mbk::kScanQueues;
     if (need > sc->scan_cap_blocks) {
@@ -470,8 +479,40 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
         hipLaunchKernelGGL((mbk::tile_todo_kernel<T, true>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
     else
         hipLaunchKernelGGL((mbk::tile_todo_kernel<T, false>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
-    MBK_HIP(ctx, hipGetLastError());
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            sc->cursors_dirty = true;
+            return fail(ctx, MBK_ERR_HIP, std::string("scan launch: ") + hipGetErrorString(e));
+        }
+    }
     return MBK_OK;
+}
+
+// Share of the window that the light pass of kernel "scan" would NOT finish: a 16 x 16 grid of its pixels is
+// iterated on the host for the 4 steps pass 1 runs (~1 000 steps, a few microseconds -- a launch costs more), and the
+// fraction still inside is returned.  A scheduling heuristic only (kernel choice of MBK_KERNEL_DEFAULT): plain
+// host doubles, no claim of bit-exactness, results never depend on it.
+static double window_heavy_share(const TileArgs &a)
+{
+    const uint32_t k = 16;
+    uint32_t inside = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        const double ci = axis_value_host(a.im, a.row0 + (uint32_t)(((uint64_t)(2u * j + 1u) * a.nrows) / (2u * k)));
+        for (uint32_t i = 0; i < k; ++i) {
+            const double cr = axis_value_host(a.re, a.col0 + (uint32_t)(((uint64_t)(2u * i + 1u) * a.ncols) / (2u * k)));
+            double zr = cr, zi = ci;
+            bool in = true;
+            for (int n = 0; n < 4 && in; ++n) {
+                const double t = zr * zr - zi * zi + cr;
+                zi = 2.0 * zr * zi + ci;
+                zr = t;
+                in = zr * zr + zi * zi < 4.0;
+            }
+            inside += in ? 1u : 0u;
+        }
+    }
+    return (double)inside / (double)(k * k);
 }
 
 static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t flags,
@@ -517,21 +558,19 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     switch (kernel) {
         case MBK_KERNEL_DEFAULT:
         case MBK_KERNEL_SCAN: {
-            // Default = whichever of the two was the better choice for the PREVIOUS launch on this stream
-            // (both leave the share of heavy blocks in pinned memory; no host round trip, and a stale or
-            // wrong hint only costs time).  With more than ~1 % of the blocks heavy the tile is bound by
-            // their arithmetic and the light blocks ride along for free in "group" (cfg2: scan 597 us,
-            // group 568); below that, "group" is bound by its 0.27 ns per workgroup and its stores, and
-            // "scan" wins (all-exterior tile: 29 us against 71).  Launches under 16 k blocks take "group",
-            // which for them is a single kernel in image order (cfg1: 20 us, scan 24).
+            // Default = a deterministic function of the window (round 3; rounds 1-2 followed the heavy share the
+            // PREVIOUS launch on the stream had reported, which made a launch's time depend on history and sent every
+            // tile after a change -- a real pyramid alternates -- to the wrong kernel).  window_heavy_share probes
+            // 256 pixels of the window for the 4 steps the light pass runs.  With more than ~1 %
+            // (MBK_OPT_HEAVY_SHARE) of them unfinished the tile is bound by the arithmetic of its heavy blocks and the
+            // light ones ride along for free in "group" (cfg2: scan 597 us, group 568); below that "group" is bound
+            // by its 0.27 ns per workgroup and its stores, and "scan" wins (all-exterior tile: 29 us against 71).
+            // Launches under 16 k blocks take "group", which for them is a single kernel in image order (cfg1: 20
+            // us, scan 24).  heavy_share = 0 forces "group", 65536 forces "scan".
             if (kernel == MBK_KERNEL_DEFAULT) {
                 if ((uint64_t)((a.ncols + 7u) / 8u) * ((a.nrows + 7u) / 8u) < 16384u)
                     return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
-                StreamScratch *sc = nullptr;
-                rc = get_scratch(ctx, stream, &sc);
-                if (rc != MBK_OK) return rc;
-                const uint32_t share = sc->h_hint[1];
-                if (share != 0xffffffffu && share > ctx->opt[MBK_OPT_HEAVY_SHARE])
+                if (window_heavy_share(a) * 65536.0 > (double)ctx->opt[MBK_OPT_HEAVY_SHARE] || ctx->opt[MBK_OPT_HEAVY_SHARE] == 0u)
                     return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
             }
             return f32 ? launch_scan_t<float>(ctx, a, safe, stream) : launch_scan_t<double>(ctx, a, safe, stream);
@@ -569,10 +608,10 @@ static int ensure_buffers(mbk_ctx *ctx, Slot &sl, size_t px)
     return MBK_OK;
 }
 
-static int launch_reduce(mbk_ctx *ctx, Slot &sl, const int32_t *d_counts, const uint8_t *d_bytes, uint64_t n,
-                         uint32_t mrd, hipStream_t stream)
+static int launch_reduce(mbk_ctx *ctx, ReduceSlot *d_red, ReduceSlot *h_red, const int32_t *d_counts, const uint8_t *d_bytes,
+                         uint64_t n, uint32_t mrd, hipStream_t stream)
 {
-    MBK_HIP(ctx, hipMemsetAsync(sl.d_red, 0, sizeof(ReduceSlot) * mbk::kReduceSlots, stream));
+    MBK_HIP(ctx, hipMemsetAsync(d_red, 0, sizeof(ReduceSlot) * mbk::kReduceSlots, stream));
     const bool vec = n >= 1024u && ((uintptr_t)d_counts & 15u) == 0u && ((uintptr_t)d_bytes & 3u) == 0u;
     uint64_t blocks = ((vec ? n / 4u : n) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -580,27 +619,32 @@ static int launch_reduce(mbk_ctx *ctx, Slot &sl, const int32_t *d_counts, const 
     // four pixels per lane and trip; the scalar kernel serves unaligned sub-buffers and tiny inputs
     if (vec && d_counts && d_bytes)
         hipLaunchKernelGGL((mbk::reduce_vec_kernel<true, true>), dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
-                           d_bytes, n, mrd, sl.d_red);
+                           d_bytes, n, mrd, d_red);
     else if (vec && d_counts)
         hipLaunchKernelGGL((mbk::reduce_vec_kernel<true, false>), dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
-                           d_bytes, n, mrd, sl.d_red);
+                           d_bytes, n, mrd, d_red);
     else if (vec && d_bytes)
         hipLaunchKernelGGL((mbk::reduce_vec_kernel<false, true>), dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
-                           d_bytes, n, mrd, sl.d_red);
+                           d_bytes, n, mrd, d_red);
     else
         hipLaunchKernelGGL(mbk::reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_counts,
-                           d_bytes, n, mrd, sl.d_red);
+                           d_bytes, n, mrd, d_red);
     MBK_HIP(ctx, hipGetLastError());
-    MBK_HIP(ctx, hipMemcpyAsync(sl.h_red, sl.d_red, sizeof(ReduceSlot) * mbk::kReduceSlots, hipMemcpyDeviceToHost, stream));
+    MBK_HIP(ctx, hipMemcpyAsync(h_red, d_red, sizeof(ReduceSlot) * mbk::kReduceSlots, hipMemcpyDeviceToHost, stream));
     return MBK_OK;
+}
+static int launch_reduce(mbk_ctx *ctx, Slot &sl, const int32_t *d_counts, const uint8_t *d_bytes, uint64_t n,
+                         uint32_t mrd, hipStream_t stream)
+{
+    return launch_reduce(ctx, sl.d_red, sl.h_red, d_counts, d_bytes, n, mrd, stream);
 }
 
 // the partial results of a finished reduction (the stream has been synchronised), added up
-static ReduceOut reduce_total(const Slot &sl)
+static ReduceOut reduce_total(const ReduceSlot *h_red)
 {
     ReduceOut t = {};
     for (uint32_t k = 0; k < mbk::kReduceSlots; ++k) {
-        const ReduceOut &r = sl.h_red[k].r;
+        const ReduceOut &r = h_red[k].r;
         t.pixel_iterations += r.pixel_iterations;
         t.never_pixels += r.never_pixels;
         t.run_starts += r.run_starts;
@@ -610,14 +654,20 @@ static ReduceOut reduce_total(const Slot &sl)
     return t;
 }
 
-static void fill_stats_from_reduce(const Slot &sl, mbk_stats *s, bool have_bytes)
+static ReduceOut reduce_total(const Slot &sl) { return reduce_total(sl.h_red); }
+
+static void fill_stats_from_reduce(const ReduceSlot *h_red, mbk_stats *s, bool have_bytes)
 {
-    const ReduceOut t = reduce_total(sl);
+    const ReduceOut t = reduce_total(h_red);
     s->pixel_iterations = t.pixel_iterations;
     s->never_pixels = t.never_pixels;
     s->all_bytes_zero = have_bytes && t.any_byte_not_zero == 0 ? 1u : 0u;
     s->all_bytes_one = have_bytes && t.any_byte_not_one == 0 ? 1u : 0u;
     s->rle_runs = have_bytes ? t.run_starts : 0ull;
+}
+static void fill_stats_from_reduce(const Slot &sl, mbk_stats *s, bool have_bytes)
+{
+    fill_stats_from_reduce(sl.h_red, s, have_bytes);
 }
 
 // ------------------------------------- C ABI ---------------------------------------------------
@@ -656,7 +706,8 @@ int mbk_create(int device, mbk_ctx **out)
     static const uint32_t kDefaults[MBK_OPT_COUNT_] = {
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
-        /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u};
+        /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
+        /* PROBE_MID */ 6u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -734,6 +785,13 @@ int mbk_get_device_info(mbk_ctx *ctx, mbk_device_info *info)
     info->clock_mhz = ctx->prop.clockRate / 1000;
     info->wavefront_size = ctx->prop.warpSize;
     info->total_mem = ctx->prop.totalGlobalMem;
+    return MBK_OK;
+}
+
+int mbk_device_pci_bus_id(mbk_ctx *ctx, char *buf, int len)
+{
+    if (!ctx || !buf || len < 16) return fail(ctx, MBK_ERR_INVALID, "buffer of at least 16 bytes needed");
+    MBK_HIP(ctx, hipDeviceGetPCIBusId(buf, len, ctx->device));
     return MBK_OK;
 }
 
@@ -926,6 +984,8 @@ int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, ui
 {
     if (!ctx || !view || !h_smooth) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
     MBK_HIP(ctx, hipSetDevice(ctx->device));
+    // the synchronous calls run on slot 0: its buffers, events and reduction scratch belong to a tile in flight
+    if (ctx->s[0].busy) return fail(ctx, MBK_ERR_INVALID, "slot 0 has a tile in flight: call mbk_wait first");
     bool dummy;
     int rc = validate_view(ctx, view, &dummy);
     if (rc != MBK_OK) return rc;
@@ -966,6 +1026,7 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
 {
     if (!ctx || !h_out || !size || !codec) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
     MBK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->s[0].busy) return fail(ctx, MBK_ERR_INVALID, "slot 0 has a tile in flight: call mbk_wait first");
     const size_t n = ctx->last_px;
     if (n == 0) return fail(ctx, MBK_ERR_INVALID, "no tile with quantised bytes has been computed on this ctx");
     const uint32_t nblocks = (uint32_t)((n + mbk::kRleBlock - 1) / mbk::kRleBlock);
@@ -1034,6 +1095,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_RF_BATCH: ok = value >= 1u && value <= 64u; break;
         case MBK_OPT_RF_WAVES: ok = value >= 1u && value <= 8u; break;
         case MBK_OPT_CYCLE_DETECT: ok = value <= 1u; break;
+        case MBK_OPT_PROBE_MID: ok = value >= 2u && value <= 65537u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");
@@ -1081,11 +1143,19 @@ int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_
     if (!ctx || !d_counts || !stats) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
     MBK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    int rc = launch_reduce(ctx, ctx->s[0], d_counts, nullptr, n, mrd, s);
+    // partial results live in the STREAM's scratch (not in slot 0's: a tile in flight on slot 0 reduces into those)
+    StreamScratch *sc = nullptr;
+    int rc = get_scratch(ctx, s, &sc);
+    if (rc != MBK_OK) return rc;
+    if (!sc->d_red) {
+        MBK_HIP(ctx, hipMalloc((void **)&sc->d_red, sizeof(ReduceSlot) * mbk::kReduceSlots));
+        MBK_HIP(ctx, hipHostMalloc((void **)&sc->h_red, sizeof(ReduceSlot) * mbk::kReduceSlots, hipHostMallocDefault));
+    }
+    rc = launch_reduce(ctx, sc->d_red, sc->h_red, d_counts, nullptr, n, mrd, s);
     if (rc != MBK_OK) return rc;
     MBK_HIP(ctx, hipStreamSynchronize(s));
     std::memset(stats, 0, sizeof(*stats));
-    fill_stats_from_reduce(ctx->s[0], stats, false);
+    fill_stats_from_reduce(sc->h_red, stats, false);
     return MBK_OK;
 }
 

@@ -50,8 +50,9 @@ struct TileArgs {
                           // lie wholly inside the window, hold neither axis' pinned last sample, and both steps
                           // are non-zero: their coordinates are fl(fl(k*step)+start), no per-lane edge handling
     uint32_t perm_mul;    // workgroup order: block = (blockIdx * perm_mul) mod gridDim (1 = row-major)
-    const uint32_t *order; // optional dispatch order (heavy-first list from classify_blocks_kernel); an entry is
-                           // (block row << 16) | workgroup column -- the host offers it only when both fit 16 bits
+    const uint32_t *order; // optional dispatch order (three-class list from classify_blocks_kernel, whose comment has
+                           // the layout); an entry is (block row << 16) | workgroup column -- the host offers it only
+                           // when both fit 16 bits
     uint32_t *heavy_hint;  // optional, pinned host memory: with `order`, workgroup 0 reports the share of
                            // probe-heavy regions (x 65536) -- next launch's kernel choice (mbk_api.hip)
     int32_t *counts;      // may be null
@@ -248,12 +249,19 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     // Dispatch order != image order when an order list is given (heavy-first, classify_blocks_kernel)
     // or perm_mul != 1 (multiplicative permutation, coprime to the grid size).
     uint32_t bx, by;
+    uint32_t n_heavy = 0u;
     if (p.order) {
-        const uint32_t e = p.order[blockIdx.x];   // packed by the classify kernel: no division here
+        // three classes (classify_blocks_kernel): heavy at the front of the list, light filled in from its back,
+        // and the middle class in a list of its own right behind the three counters
+        n_heavy = p.order[gridDim.x];
+        const uint32_t n_mid = p.order[gridDim.x + 2u];
+        const uint32_t j = blockIdx.x;
+        const uint32_t e = (j >= n_heavy && j < n_heavy + n_mid) ? p.order[gridDim.x + 3u + (j - n_heavy)]
+                                                                 : p.order[j];   // packed: no division here
         by = e >> 16;
         bx = e & 0xffffu;
-        if (p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)   // cursors sit behind the list
-            *p.heavy_hint = (uint32_t)(((uint64_t)p.order[gridDim.x] << 16) / gridDim.x);
+        if (p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)
+            *p.heavy_hint = (uint32_t)(((uint64_t)n_heavy << 16) / gridDim.x);
     } else {
         const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
         by = blk / p.blocks_x;
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     const uint32_t lc = wcol * 8u + (lane & 7u);
     const uint32_t lr = by * 8u + (lane >> 3);
     // the blocks the heavy-first probe put at the front of the dispatch order take the 16-step groups
-    const bool long_groups = kGroup == 16 && (!p.order || blockIdx.x < p.order[gridDim.x]);   // wave-uniform
+    const bool long_groups = kGroup == 16 && (!p.order || blockIdx.x < n_heavy);   // wave-uniform
     const bool interior = wcol < p.fast_bx_end && by < p.fast_by_end;                        // wave-uniform
     block_pixel<T, kFmaDouble, kGroup, kCycle>(p, lc, lr, long_groups, interior);
 }
@@ -275,19 +283,27 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
 // (~10 us each, almost no VALU work) before the next long one arrives, so the SIMDs run with ~5
 // useful waves instead of 8, and the tile ends with a drain of long waves and nothing to overlap it.
 // Measured on cfg2 (profiles/microbench/occupancy_trace.hip): heavy-first order -10 % kernel time.
-// This kernel probes ONE pixel per workgroup region (its centre) for `probe_steps` steps and
-// builds the order: regions whose probe did not escape go to the front of `order` (atomic cursor
-// counters[0]), the others are filled in from the back (counters[1]).  It is a scheduling heuristic
-// only: a mis-classified block is merely computed earlier or later; results cannot change.
+// This kernel probes ONE pixel per workgroup region (its centre) for `probe_steps` steps and builds the
+// order in three classes (round 3; two before): "heavy" = the probe did not escape -> front of `order` (atomic
+// cursor counters[0]); "light" = the probe escaped within `mid_min` - 1 steps -> filled in from the back
+// (counters[1]); "middle" = the probe escaped later (count >= mid_min) -> a list of its own behind the counters
+// (counters[2]), dispatched between the two.  Why the middle class: scripts/dispatch_model.py (event simulation on
+// the tile's exact block durations) puts the idle share of a cfg2 launch not in the order of the in-set blocks
+// but in the ~20 000 boundary blocks whose centre pixel escapes early -- filed under "light", they were
+// dispatched last and formed the tail (makespan 1.040x the balanced ideal; 1.018x with this order).
+// It is a scheduling heuristic only: a mis-classified block is merely computed earlier or later; results
+// cannot change.  Layout: order[0 .. n) heavy from the front / light from the back, order[n .. n+3) the three
+// counters (heavy, light, middle), order[n+3 .. 2n+3) the middle list.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void classify_blocks_kernel(TileArgs p, uint32_t nregions,
-                                                                uint32_t region_w, int32_t probe_steps,
+                                                                uint32_t region_w, int32_t probe_steps, int32_t mid_min,
                                                                 uint32_t *order, uint32_t *counters)
 {
-    __shared__ uint32_t s_heavy[16], s_light[16], s_base[2];
+    __shared__ uint32_t s_cnt[3][16], s_base[3];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    bool valid = r < nregions, heavy = false;
+    const bool valid = r < nregions;
+    uint32_t cls = 1u;     // 0 heavy, 1 light, 2 middle
     uint32_t packed = 0;   // the list entry of this region: (block row << 16) | workgroup column
     if (valid) {
         const uint32_t by = r / p.blocks_x, bx = r - by * p.blocks_x;
@@ -297,34 +313,33 @@ __global__ __launch_bounds__(1024) void classify_blocks_kernel(TileArgs p, uint3
         lr = lr < p.nrows ? lr : p.nrows - 1u;
         const double cr = axis_value(p.re, p.col0 + lc), ci = axis_value(p.im, p.row0 + lr);
         const int32_t cap = p.mrd < probe_steps ? p.mrd : probe_steps;
-        heavy = cap > 1 && escape_count<true>(cr, ci, cap) == 0;
+        const int32_t cnt = cap > 1 ? escape_count<true>(cr, ci, cap) : 1;
+        cls = cnt == 0 ? 0u : (cnt >= mid_min ? 2u : 1u);
     }
-    const unsigned long long hm = __ballot(valid && heavy), lm = __ballot(valid && !heavy);
-    if (lane == 0) {
-        s_heavy[wave] = (uint32_t)__popcll(hm);
-        s_light[wave] = (uint32_t)__popcll(lm);
+    unsigned long long m[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        m[k] = __ballot(valid && cls == k);
+        if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(m[k]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t h = 0, l = 0;
-        const uint32_t nw = (blockDim.x + 63u) >> 6;
+    if (threadIdx.x < 3u) {
+        const uint32_t k = threadIdx.x, nw = (blockDim.x + 63u) >> 6;
+        uint32_t t = 0;
         for (uint32_t w = 0; w < nw; ++w) {
-            const uint32_t hw = s_heavy[w], lw = s_light[w];
-            s_heavy[w] = h;
-            s_light[w] = l;
-            h += hw;
-            l += lw;
+            const uint32_t c = s_cnt[k][w];
+            s_cnt[k][w] = t;
+            t += c;
         }
-        s_base[0] = h ? atomicAdd(&counters[0], h) : 0u;
-        s_base[1] = l ? atomicAdd(&counters[1], l) : 0u;
+        s_base[k] = t ? atomicAdd(&counters[k], t) : 0u;
     }
     __syncthreads();
     if (valid) {
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (heavy)
-            order[s_base[0] + s_heavy[wave] + (uint32_t)__popcll(hm & below)] = packed;
-        else
-            order[nregions - 1u - (s_base[1] + s_light[wave] + (uint32_t)__popcll(lm & below))] = packed;
+        const uint32_t i = s_base[cls] + s_cnt[cls][wave] + (uint32_t)__popcll(m[cls] & below);
+        if (cls == 0u) order[i] = packed;
+        else if (cls == 1u) order[nregions - 1u - i] = packed;
+        else order[nregions + 3u + i] = packed;
     }
 }
 

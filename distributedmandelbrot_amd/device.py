@@ -115,6 +115,11 @@ class MandelbrotDevice:
                 "compute_units": inf.compute_units, "clock_mhz": inf.clock_mhz,
                 "wavefront_size": inf.wavefront_size, "total_mem": inf.total_mem}
 
+    def pci_bus_id(self) -> str:
+        buf = C.create_string_buffer(32)
+        self._check(self._lib.mbk_device_pci_bus_id(self._h, buf, 32))
+        return buf.value.decode()
+
     def pinned_empty(self, shape, dtype) -> np.ndarray:
         """A numpy array over pinned host memory (freed when the device is closed)."""
         dtype = np.dtype(dtype)

@@ -94,8 +94,10 @@ def describe_stats(st) -> str:
     kind = "Never" if st.all_bytes_zero else "Immediate" if st.all_bytes_one else \
         ("RLE" if 1 + 5 * st.rle_runs < 1 + CHUNK_BYTES else "Raw")
     rate = st.pixel_iterations / st.kernel_ms / 1e6 if st.kernel_ms > 0 else 0.0
+    # pixel_iterations are the REFERENCE's iterations for this output (count, or mrd-1 for a pixel of the set); with
+    # the library's cycle test on, fewer steps are executed, so the rate is labelled reference-equivalent
     return (f"kernel {st.kernel_ms:.3f} ms, D2H {st.d2h_ms:.3f} ms, {st.pixel_iterations / 1e9:.2f} G pixel-iterations "
-            f"({rate:.0f} G/s), {st.never_pixels} in-set pixels, stored as {kind}")
+            f"({rate:.0f} G/s reference-equivalent), {st.never_pixels} in-set pixels, stored as {kind}")
 
 
 def _recv_exact(sock: socket.socket, n: int) -> bytes:
@@ -283,8 +285,12 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
         more = True
         while more or any(inflight):
             if more and not errors and (max_tiles is None or leased < max_tiles) and (take is None or take()):
-                workload = request_workload(addr, port)
-                if workload is None:
+                try:
+                    workload = request_workload(addr, port)
+                except BaseException as e:   # e.g. connection refused while the server restarts: stop leasing, but
+                    errors.append(e)         # finish (wait for + send) the tiles already leased; re-raised below
+                    workload, more = None, False
+                if workload is None and more:
                     log("No workload was available, ending program")
                     more = False
             else:
@@ -324,8 +330,8 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
     if devices is None:
         from .device import device_count
         devices = list(range(device_count()))
-        if not devices:
-            raise RuntimeError("no gfx950 GPU visible and no CPU fallback exists")
+    if not devices:   # also an explicitly empty list: a farm node that silently does nothing is a misconfiguration
+        raise RuntimeError("no gfx950 GPU visible and no CPU fallback exists")
 
     done = [0] * len(devices)
     errors: List[BaseException] = []
@@ -375,11 +381,8 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
         addr = input("Server Addr> ")
         port = int(input("Server Port> "))
     devices = [int(x) for x in argv[2].split(",")] if len(argv) >= 3 else None
-    if devices is None:
-        from .device import device_count
-        devices = list(range(device_count()))
     # every listed GPU gets its own pipelined feeder (an explicit single index -- `worker ADDR PORT 3` --
-    # runs on THAT GPU; round 1 sent it to GPU 0)
+    # runs on THAT GPU; round 1 sent it to GPU 0); no list = every visible GPU, and run_farm raises when there is none
     run_farm(addr, port, devices)
     log_stats = dict(stats)
     print("tiles:", log_stats)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MBK_ABI_VERSION 2
+#define MBK_ABI_VERSION 3
 
 /* DataChunk.cs:20 (dataChunkRange), WorkerCUDA.py:80 (definition = 4096). */
 #define MBK_CHUNK_DEFINITION 4096u
@@ -44,8 +44,9 @@ enum mbk_status {
 /* flags for the compute calls */
 #define MBK_WANT_COUNTS 0x1u /* write int32 escape indices (what calc_mb_value returns, WorkerCUDA.py:39) */
 #define MBK_WANT_BYTES 0x2u  /* write the quantised uint8 (WorkerCUDA.py:96-98) -- fused on device */
-/* Kernel selection (bits 8..11).  0 = default (fastest parity-exact kernel: "scan"). Others exist so that
- * the parity tests and bench.py can A/B every shipped kernel variant; all of them are bit-exact. */
+/* Kernel selection (bits 8..11).  0 = default: "scan" or "group", decided per launch from a 256-pixel host probe of
+ * the window (MBK_OPT_HEAVY_SHARE) -- a deterministic function of the window, not of earlier launches.  The others
+ * exist so that the parity tests and bench.py can A/B every shipped kernel variant; all of them are bit-exact. */
 #define MBK_KERNEL_SHIFT 8
 #define MBK_KERNEL_MASK 0xF00u
 #define MBK_KERNEL_DEFAULT 0x000u
@@ -92,7 +93,8 @@ typedef struct mbk_view {
 typedef struct mbk_stats {
     float kernel_ms;           /* hipEvent time of the escape-time kernel launch(es) */
     float d2h_ms;              /* hipEvent time of the device->host copies */
-    uint64_t pixel_iterations; /* sum over pixels of (count if count>0 else mrd-1), from the kernel's own counts */
+    uint64_t pixel_iterations; /* sum over pixels of (count if count>0 else mrd-1), from the kernel's own counts: the
+                                  REFERENCE's iterations for this output (with the cycle test on, fewer are executed) */
     uint64_t never_pixels;     /* pixels with count == 0 (never escaped) */
     uint32_t all_bytes_zero;   /* 1 iff every quantised byte == 0: DataChunk.IsNeverChunk,     DataChunk.cs:82 */
     uint32_t all_bytes_one;    /* 1 iff every quantised byte == 1: DataChunk.IsImmediateChunk, DataChunk.cs:87 */
@@ -124,6 +126,9 @@ void mbk_destroy(mbk_ctx *ctx);
 const char *mbk_last_error(const mbk_ctx *ctx);
 
 int mbk_get_device_info(mbk_ctx *ctx, mbk_device_info *info);
+/* PCI bus id of the ctx's GPU as "dddd:bb:dd.f" (hipDeviceGetPCIBusId); len >= 16.  What a multi-GPU job reports
+ * per rank so that a reader can tell N distinct GPUs took part (there is no RCCL communicator to ask). */
+int mbk_device_pci_bus_id(mbk_ctx *ctx, char *buf, int len);
 
 /* Pinned host memory for result buffers (direct DMA target of the D2H copy).  Optional: any host
  * pointer is accepted by the compute calls. */
@@ -177,6 +182,9 @@ int mbk_view_launch_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uin
 int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t flags,
                             int32_t *h_counts, double *h_smooth, mbk_stats *stats);
 
+/* NOTE on slot 0: the synchronous calls (mbk_view_compute, mbk_datachunk, mbk_view_compute_smooth,
+ * mbk_quantise_counts) and mbk_serialize_last work on slot 0's buffers; while a tile submitted on slot 0 has not
+ * been waited for they return MBK_ERR_INVALID instead of touching them. */
 /*
  * Two tiles in flight per context ("double-buffered streams": the D2H of one tile overlaps the kernel
  * of the next; each slot has its own HIP stream, events and device buffers).  mbk_datachunk_submit
@@ -217,17 +225,19 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
  * range.  Defaults in brackets.
  */
 enum mbk_option {
-    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] heavy-first list */
+    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] three-class list
+                              (probe never escaped / escaped late / escaped early) */
     MBK_OPT_WAVES_PER_WG,  /* asm/group: 8x8 blocks per workgroup: [1], 2, 4 */
-    MBK_OPT_GROUP_STEPS,   /* group / scan pass 2: steps per grouped bailout test: 4, 8, [16] (16 applies to the blocks
-                              classified as interior -- probe-heavy / dense --, the rest keep 8) */
+    MBK_OPT_GROUP_STEPS,   /* group: steps per grouped bailout test: 4, 8, [16] (16 applies to the blocks classified as
+                              interior -- probe-heavy / dense --, the rest keep 8).  Scan pass 2 and the fp32 loops have no
+                              4-step form: there 4 means 8 (and the cycle test needs >= 8, so 4 in "group" runs without it) */
     MBK_OPT_EXACT_STEPS,   /* group / scan pass 2: steps tested one by one before the grouped test takes over: 0..4096 [8] */
     MBK_OPT_PROBE_STEPS,   /* asm/group: depth of the heavy-first probe: 2..65536 [32] */
     MBK_OPT_SCAN_WAVES,    /* scan: resident waves per SIMD of pass 1: 1..[8] */
     MBK_OPT_SCAN_XCD_MAP,  /* scan: XCD-aware block-column order (a 128-byte output line is completed in one L2): 0, [1] */
     MBK_OPT_SCAN_COL_PERIOD, /* scan: sweeps a pass-1 wave stays in one block column before jumping to a far one: 0 (never) .. 65536 [4] */
-    MBK_OPT_HEAVY_SHARE,   /* default kernel: share of heavy blocks (x 65536) in the previous launch on the stream above
-                              which the next one uses "group" instead of "scan": 0..65536 [655 = 1 %] */
+    MBK_OPT_HEAVY_SHARE,   /* default kernel: share (x 65536) of the window's probe pixels still inside after 4 steps above
+                              which the launch uses "group" instead of "scan": 0 (always group) .. 65536 (always scan) [655 = 1 %] */
     MBK_OPT_RF_LIVEMIN,    /* refill: refill when this many lanes or fewer are live: 0..63 [48] */
     MBK_OPT_RF_PATIENCE,   /* refill: steps between forced refill checks: 16..2^20 [256] */
     MBK_OPT_RF_BATCH,      /* refill: blocks per queue pop: 1..64 [1] */
@@ -236,6 +246,9 @@ enum mbk_option {
                               (zr, zi) bit pattern repeats an earlier state of its own orbit -- the step map is a
                               deterministic function of those bits, so the reference's loop provably runs to mrd-1 and
                               returns 0.  Same counts, fewer executed steps on tiles that hold part of the set: 0, [1] */
+    MBK_OPT_PROBE_MID,     /* asm/group: a block whose probe pixel escapes at step >= this value goes to the middle dispatch
+                              class (after the blocks whose probe never escaped, before the rest): 2..65537 [6]; a value
+                              above probe_steps leaves the middle class empty = the two-class order of round 2 */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

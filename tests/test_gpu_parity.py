@@ -400,6 +400,8 @@ OPTION_MATRIX = [
     ("refill", {"rf_batch": 4, "rf_waves": 2}),
     ("group", {"cycle_detect": 0}), ("scan", {"cycle_detect": 0}), ("default", {"cycle_detect": 0}),
     ("group", {"cycle_detect": 0, "group_steps": 8, "waves_per_wg": 2}), ("group", {"cycle_detect": 1, "exact_steps": 0, "order": 0}),
+    ("group", {"probe_mid": 2}), ("group", {"probe_mid": 65537, "cycle_detect": 0}), ("default", {"probe_mid": 20, "probe_steps": 64}),
+    ("default", {"heavy_share": 0}), ("default", {"heavy_share": 65536}),
 ]
 
 
@@ -492,10 +494,11 @@ def test_pipelined_worker_on_gpu_against_fake_distributer(gpu, golden):
             assert hashlib.sha256(srv.completed[w].tobytes()).hexdigest() == str(golden[f"full/{key}/bytes_sha256"])
 
 
-def test_default_kernel_follows_the_heavy_share_hint(oracle):
-    """The default kernel is chosen from what the previous launch on the stream reported (pinned-memory hint,
-    no host round trip): light tiles -> "scan", heavy tiles -> "group".  Whatever it picks, and in whatever
-    order tiles arrive, results are bit-exact; a threshold of 0 / 65536 forces either path."""
+def test_default_kernel_choice_any_arrival_order(oracle):
+    """The default kernel is chosen per launch from a 256-pixel host probe of the window (round 3; rounds 1-2 used
+    what the previous launch on the stream had reported): light tiles -> "scan", heavy tiles -> "group".  Whatever
+    it picks, and in whatever order tiles arrive, results are bit-exact; a threshold of 0 / 65536 forces either
+    path."""
     from distributedmandelbrot_amd import MandelbrotDevice
     heavy = (View(-0.2, -0.1, 0.2, 0.2, 1024, 1024), 300)      # inside the cardioid: every block heavy
     light = (View(-2.0, -2.0, 1.0, 1.0, 1024, 1024), 300)      # far exterior: nothing deferred
@@ -610,3 +613,142 @@ def test_stats_reduction_vector_and_scalar_paths(gpu, oracle):
         assert np.array_equal(b, ob) and st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum())
         assert st.rle_runs == len(rle_runs(ob.reshape(-1))[0]), (w, h, mrd)
         assert st.all_bytes_zero == bool((ob == 0).all()) and st.all_bytes_one == bool((ob == 1).all())
+
+
+# ------------------------------------------------------------------------------------------------------
+# Round 3
+# ------------------------------------------------------------------------------------------------------
+
+def test_default_kernel_choice_is_history_independent():
+    """The kernel of a default launch depends on its window only: an all-exterior tile costs the same (the light
+    pass, tens of microseconds) whether the launch before it was light or heavy.  Rounds 1-2 picked from the previous
+    launch's report and sent the first light tile after a heavy one down the one-workgroup-per-block path (~70 us)."""
+    from distributedmandelbrot_amd import MandelbrotDevice
+    with MandelbrotDevice(0) as dev:
+        buf = dev.pinned_empty((16777216,), np.uint8)
+        for _ in range(3):
+            dev.datachunk(4, 1000, 0, 0, out_bytes=buf)                       # warm
+        after_light = min(dev.datachunk(4, 1000, 0, 0, out_bytes=buf)[2].kernel_ms for _ in range(5))
+        after_heavy = []
+        for _ in range(5):
+            dev.datachunk(4, 1000, 1, 2, out_bytes=buf)                       # half of it inside the set
+            after_heavy.append(dev.datachunk(4, 1000, 0, 0, out_bytes=buf)[2].kernel_ms)
+        assert after_light < 0.060, after_light
+        assert min(after_heavy) < 1.3 * after_light + 0.005, (after_light, after_heavy)
+
+
+def test_slot0_users_refuse_while_a_tile_is_in_flight(gpu, golden):
+    """mbk_view_compute_smooth, mbk_serialize_last, mbk_quantise_counts and the synchronous compute calls work on
+    slot 0's buffers, events and reduction scratch: with a tile in flight there they return MBK_ERR_INVALID and
+    leave it alone; mbk_reduce_counts on a caller stream has scratch of its own and may run.  The tile then
+    arrives intact."""
+    import torch
+    from distributedmandelbrot_amd import MbkError
+    buf = gpu.pinned_empty((16777216,), np.uint8)
+    small = View(-2.0, -1.5, 3.0, 3.0, 64, 64)
+    gpu.datachunk(4, 256, 0, 0, out_bytes=buf)          # so that serialize_last has a "last tile"
+    d = torch.from_numpy(np.arange(4096, dtype=np.int32)).to("cuda:0")
+    gpu.submit_datachunk(0, 10, 1024, 3, 5, buf)        # boundary-rich golden tile: a few hundred microseconds
+    with pytest.raises(MbkError):
+        gpu.compute_view_smooth(small, 100)
+    with pytest.raises(MbkError):
+        gpu.serialize_last()
+    with pytest.raises(MbkError):
+        gpu.quantise_counts(np.arange(10, dtype=np.int32), 100)
+    with pytest.raises(MbkError):
+        gpu.compute_view(small, 100)
+    st_r = gpu.reduce_counts(d.data_ptr(), 4096, 5000, stream=torch.cuda.current_stream().cuda_stream)
+    assert st_r.pixel_iterations == 4999 + sum(range(1, 4096)) and st_r.never_pixels == 1
+    st = gpu.wait(0)
+    assert hashlib.sha256(buf.tobytes()).hexdigest() == str(golden["full/10_1024_3_5/bytes_sha256"])
+    assert st.never_pixels == int(golden["full/10_1024_3_5/zeros"])
+    gpu.compute_view_smooth(small, 100)                 # and slot 0 is usable again
+    gpu.serialize_last()
+
+
+CFG3_LEVEL, CFG3_MRD, CFG3_IR, CFG3_II = 800000, 10000, 251270, 426364   # SURVEY 8(d): cfg3 as DataChunks
+
+
+@pytest.fixture(scope="module")
+def cfg3_chunks_oracle(oracle):
+    """The four DataChunk tiles of level 800 000 around BASELINE cfg3's centre (range 5e-6 each), from the 8-lane
+    AVX-512 evaluation of the oracle on the tiles' own geometry (WorkerCUDA.py:75-78)."""
+    if not oracle.have_avx512():
+        pytest.skip("host without AVX-512: the scalar oracle needs minutes for these tiles")
+    out = {}
+    for dr in (0, 1):
+        for di in (0, 1):
+            sr, si, rng = oracle.geometry(CFG3_LEVEL, CFG3_IR + dr, CFG3_II + di)
+            out[(dr, di)] = oracle.view_avx512(sr, si, rng, rng, 4096, 4096, CFG3_MRD)[0]
+    return out
+
+
+def test_cfg3_as_datachunk_tiles(gpu, cfg3_chunks_oracle):
+    """BASELINE cfg3 in its DataChunk form: 2 x 2 tiles of level 800 000, mrd 10000, through mbk_datachunk -- counts
+    and bytes against the oracle, and the reference's tile quirk on DEVICE output: adjacent tiles share their edge
+    (np.linspace includes the end point, so tile (ir, ii)'s last column is tile (ir+1, ii)'s first)."""
+    got = {}
+    for (dr, di), oc in cfg3_chunks_oracle.items():
+        byts, counts, st = gpu.datachunk(CFG3_LEVEL, CFG3_MRD, CFG3_IR + dr, CFG3_II + di, want_counts=True)
+        counts = counts.reshape(4096, 4096)
+        assert np.array_equal(counts, oc), ((dr, di), int((counts != oc).sum()))
+        ob = ((oc.astype(np.int64) * 256 + CFG3_MRD - 1) // CFG3_MRD).astype(np.uint8)
+        assert np.array_equal(byts.reshape(4096, 4096), ob)
+        assert st.pixel_iterations == int(np.where(oc > 0, oc, CFG3_MRD - 1).astype(np.int64).sum())
+        got[(dr, di)] = counts
+    for di in (0, 1):    # real neighbours: last column == first column
+        assert np.array_equal(got[(0, di)][:, -1], got[(1, di)][:, 0])
+    for dr in (0, 1):    # imaginary neighbours: last row == first row
+        assert np.array_equal(got[(dr, 0)][-1, :], got[(dr, 1)][0, :])
+
+
+def test_cfg3_datachunks_through_a_farm_of_two_feeders(gpu, cfg3_chunks_oracle):
+    """The same four tiles leased by the stand-in Distributer to TWO pipelined feeders (run_farm; both on GPU 0 --
+    any number of clients may pull from the one hand-out loop, Distributer.cs:335-392): every tile arrives once,
+    with the oracle's bytes."""
+    from distributedmandelbrot_amd import worker
+    from distributedmandelbrot_amd.server import Distributer
+
+    class Window(Distributer):          # hand out exactly the 2 x 2 tiles around cfg3's centre
+        def _next_needed(self):
+            import time as _t
+            now = _t.monotonic()
+            self.leases = [(w, t) for w, t in self.leases if now < t]
+            leased = {w for w, _ in self.leases} | set(self.receiving)
+            for dr in (0, 1):
+                for di in (0, 1):
+                    w = (CFG3_LEVEL, CFG3_MRD, CFG3_IR + dr, CFG3_II + di)
+                    if (w[0], w[2], w[3]) not in self.completed and w not in leased:
+                        return w
+            return None
+
+    got = {}
+
+    class Keep:
+        def completed(self):
+            return []
+
+        def save_chunk(self, level, ir, ii, payload):
+            got[(ir - CFG3_IR, ii - CFG3_II)] = np.array(payload, copy=True)
+
+    with Window([(CFG3_LEVEL, CFG3_MRD)], store=Keep()) as dist:
+        done = worker.run_farm("127.0.0.1", dist.port, devices=[0, 0], log=lambda *a: None)
+        assert sum(done) == 4 and dist.received == 4 and not dist.rejected
+    for key, oc in cfg3_chunks_oracle.items():
+        ob = ((oc.astype(np.int64) * 256 + CFG3_MRD - 1) // CFG3_MRD).astype(np.uint8)
+        assert np.array_equal(got[key].reshape(4096, 4096), ob), key
+
+
+def test_pci_bus_id_and_queue_tiles_of_the_bench(gpu, oracle):
+    """What bench.py's multi-GPU line reports per rank, and the tiles of its --shard queue job: windows of one
+    grid x 4096 view are bit-identical to the oracle's evaluation of the same window."""
+    import re
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", gpu.pci_bus_id())
+    grid = 8
+    qview = View(-2.0, -1.5, 3.0, 3.0, 4096 * grid, 4096 * grid)
+    for tr, ti, rows in ((0, 0, 64), (3, 4, 48), (5, 3, 32), (7, 7, 64)):
+        window = (tr * 4096, ti * 4096 + 1000, 4096, rows)
+        c, _, st = gpu.compute_view(qview, 1000, window=window, want_bytes=False)
+        oc, _, total = oracle.view(qview.start_r, qview.start_i, qview.range_r, qview.range_i, qview.width, qview.height,
+                                   1000, window=window, want_bytes=False)
+        assert np.array_equal(c, oc) and st.pixel_iterations == total, (tr, ti)

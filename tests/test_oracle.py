@@ -218,7 +218,7 @@ def test_cycle_retirement_claim(oracle):
     saved = 0
     for sr, si, rr, ri, w, h, mrd in cases:
         strict, _, _ = oracle.view(sr, si, rr, ri, w, h, mrd, want_bytes=False)
-        for first, check in ((8, 16), (0, 1), (8, 32), (3, 7)):
+        for first, check in ((8, 8), (8, 16), (0, 1), (8, 32), (3, 7)):   # (8, 8) = the kernels' schedule
             counts, executed = oracle.view_cycle(sr, si, rr, ri, w, h, mrd, first=first, check=check)
             assert np.array_equal(counts, strict), (sr, si, mrd, first, check)
             ref_steps = np.where(strict > 0, strict, mrd - 1)

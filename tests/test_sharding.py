@@ -123,13 +123,14 @@ def test_bench_distributed_path_gloo_world2():
     env = dict(os.environ, MBK_BENCH_FAKE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1"]
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--shard", "own"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["launcher"] == "torch.distributed.run" and len(rec["config"]["ranks_seen"]) == 2
     assert rec["data"].startswith("synthetic") and rec["higher_is_better"] is True
     # fake backend: every rank reports 1e9 pixel-iterations per step -> aggregate = 2e9 * steps / time
     assert rec["config"]["fake_backend"] is True
@@ -157,6 +158,53 @@ def test_bench_bands_dynamic_cursor_gloo_world2():
     assert cfg["bands_exactly_once"] is True
     assert sum(cfg["bands_per_rank"]) == 3 * 32 and min(cfg["bands_per_rank"]) > 0
     assert not os.path.exists(os.path.join("/dev/shm", "mbk_cursor_%d_none" % port))
+
+
+def test_bench_self_launch_queue_default_world2():
+    """`python bench.py --gpus 2` -- the driver's plain command, no launcher around it -- starts its own two ranks
+    and prints ONE JSON line.  The N > 1 default is the north star's partition: a fixed set of tiles per step that
+    the ranks pull from one shared cursor (strong scaling), each ticket taken exactly once, both ranks fed, and
+    `ranks_seen` says who took part.  Stub compute (MBK_BENCH_FAKE=1): there is no GPU here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["MBK_BENCH_FAKE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "strong" and cfg["shard"] == "queue"
+    assert cfg["launcher"] == "bench.py self-launch" and cfg["control_backend"] == "gloo"
+    assert cfg["tiles_per_step"] == 64 and cfg["grid"] == 8 and cfg["tiles_exactly_once"] is True
+    assert sum(cfg["tiles_per_rank"]) == 3 * 64 and min(cfg["tiles_per_rank"]) > 0
+    seen = cfg["ranks_seen"]
+    assert sorted(r["rank"] for r in seen) == [0, 1] and len({r["pid"] for r in seen}) == 2
+    assert all(k in seen[0] for k in ("host", "device", "pci_bus_id", "gpu_index", "local_rank"))
+    assert len(cfg["rank_finish_ms"]) == 2 and rec["roofline"]["traffic"] is None
+    # the stub's per-tile work is 1e7 * (1 + t % 3): the census must have measured every tile once
+    per_step = sum(10 ** 7 * (1 + t % 3) for t in range(64))
+    assert abs(rec["value"] - per_step * 3 / (rec["ms_per_step"] * 3 / 1e3) / 1e9) / rec["value"] < 1e-6
+
+
+def test_bench_self_launch_reports_a_dead_rank():
+    """A rank that dies must not leave the others hanging in a barrier: the launcher stops them and exits non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MBK_BENCH_FAKE="1", MBK_BENCH_FAKE_DIE_RANK="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "rank 1 exited" in out.stderr
+
+
+def test_bench_queue_mode_single_rank_fake():
+    """--shard queue at N = 1 is the same-mode first point of the scaling curve."""
+    env = dict(os.environ, MBK_BENCH_FAKE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shard", "queue", "--grid", "3", "--steps", "2"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "strong" and rec["config"]["tiles_per_step"] == 9
+    assert rec["config"]["tiles_exactly_once"] is True and rec["config"]["tiles_per_rank"] == [18]
 
 
 def _cursor_worker(name, n, q):
@@ -211,6 +259,8 @@ def test_bench_json_contract_single_rank_fake():
     # the headline is the strict leg (every iteration executed); the cycle-test leg needs a GPU and is absent here
     assert rec["config"]["cycle_test"].startswith("off for value and roofline") and rec["config"]["cycle_leg_error"] is None
     assert "cycle_detection" not in rec
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel_ms_median"):
         assert key in rec["roofline"], key
+    assert rec["scaling"] == "weak" and rec["config"]["shard"] == "own" and rec["config"]["launcher"] == "single process"
+    assert len(rec["config"]["ranks_seen"]) == 1 and rec["config"]["distinct_gpus"] == 1
     assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-12
