@@ -762,6 +762,29 @@ def main():
             }
         if world == 1 and own_mode and not fake and not args.no_extras and args.workload == "cfg2" and not smooth:
             # beside the headline (never in `value`): the end-to-end tile rate, and the N > 1 default job on this GPU
+            try:   # the same strict steps with TWO launches in flight (two streams): what a two-slot worker context does
+                s2 = torch.cuda.Stream()
+                buf2 = torch.empty(npix, dtype=torch.int32, device=f"cuda:{gpu_index}")
+
+                def launch2(k):
+                    dev.launch_view(view, mrd, d_counts=(d_counts_all[0] if k % 2 == 0 else buf2).data_ptr(),
+                                    stream=(streams[0] if k % 2 == 0 else s2).cuda_stream, kernel=args.kernel,
+                                    precision=args.precision)
+                for k in range(max(args.warmup, 4)):
+                    launch2(k)
+                sync()
+                t2 = time.perf_counter()
+                for k in range(args.steps):
+                    launch2(k)
+                sync()
+                dt2 = time.perf_counter() - t2
+                rec["two_streams"] = {"what": "the headline's steps (cycle test off) issued alternately on two streams: the tail of one "
+                                              "launch overlaps the head of the next; per-launch events no longer isolate a kernel, so "
+                                              "this is a wall-clock rate only",
+                                      "value": iters_per_step * args.steps / dt2 / 1e9, "unit": "G pixel-iterations/s",
+                                      "ms_per_step": dt2 / args.steps * 1e3, "ratio_to_headline_value": (iters_per_step * args.steps / dt2 / 1e9) / rec["value"]}
+            except Exception as e:   # noqa: BLE001
+                rec["two_streams"] = {"error": repr(e)}
             try:
                 dev.set_option("cycle_detect", 1)
                 rec["end_to_end"] = end_to_end(dev)

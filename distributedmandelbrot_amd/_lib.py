@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libmbk_hip.so")
 
-MBK_OK, MBK_ERR_INVALID, MBK_ERR_NO_DEVICE, MBK_ERR_HIP, MBK_ERR_NOMEM = range(5)
+MBK_OK, MBK_ERR_INVALID, MBK_ERR_NO_DEVICE, MBK_ERR_HIP, MBK_ERR_NOMEM, MBK_ERR_NET = range(6)
 MBK_WANT_COUNTS = 0x1
 MBK_WANT_BYTES = 0x2
 MBK_KERNEL_DEFAULT = 0x000
@@ -28,7 +28,7 @@ KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MB
 # enum mbk_option (include/mbk.h), in order
 OPTIONS = {name: i for i, name in enumerate(
     ["order", "waves_per_wg", "group_steps", "exact_steps", "probe_steps", "scan_waves", "scan_xcd_map", "scan_col_period", "heavy_share",
-     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid"])}
+     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid", "prepass_overlap"])}
 MBK_PRECISION_F32 = 0x1000
 MBK_LAZY_UNIFORM = 0x2000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
@@ -59,6 +59,24 @@ class mbk_device_info(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64),
                 ("compute_units", C.c_int), ("clock_mhz", C.c_int),
                 ("wavefront_size", C.c_int), ("total_mem", C.c_uint64)]
+
+
+class mbk_worker_report(C.Structure):
+    _fields_ = [("leased", C.c_uint64), ("accepted", C.c_uint64), ("rejected", C.c_uint64), ("resets", C.c_uint64),
+                ("uniform_tiles", C.c_uint64), ("pixel_iterations", C.c_uint64),
+                ("kernel_ms_sum", C.c_double), ("seconds", C.c_double)]
+
+
+FEEDER_SUBMIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
+FEEDER_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(mbk_stats))
+FEEDER_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
+FEEDER_RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+FEEDER_ON_TILE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint32 * 4), C.POINTER(mbk_stats), C.c_int)
+
+
+class mbk_feeder_ops(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("submit", FEEDER_SUBMIT), ("wait", FEEDER_WAIT), ("alloc", FEEDER_ALLOC),
+                ("release", FEEDER_RELEASE), ("on_tile", FEEDER_ON_TILE)]
 
 
 # symbol -> (restype, argtypes); this table is also what tests/test_abi.py checks against mbk.h
@@ -99,6 +117,10 @@ SIGNATURES = {
     "mbk_quantise_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "mbk_reduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                     C.POINTER(mbk_stats)]),
+    "mbk_worker_run": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint16, C.c_uint64, C.c_uint32,
+                                 C.POINTER(mbk_worker_report)]),
+    "mbk_feeder_run": (C.c_int, [C.POINTER(mbk_feeder_ops), C.c_char_p, C.c_uint16, C.c_uint64, C.c_uint32,
+                                 C.POINTER(mbk_worker_report)]),
 }
 
 _lib = None

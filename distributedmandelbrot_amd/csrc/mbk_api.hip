@@ -21,6 +21,7 @@
 #include "mbk_refill.h"
 #include "mbk_persist.h"
 #include "mbk_scan.h"
+#include "mbk_feeder.h"
 
 using mbk::Axis;
 using mbk::ReduceOut;
@@ -34,8 +35,16 @@ using mbk::WorkQueues;
 // however many streams the caller uses (round 1 shared a ring of 8 across all streams).
 struct StreamScratch {
     hipStream_t stream = nullptr;
-    uint32_t *d_order = nullptr;  // heavy-first dispatch order (+2 cursors) of kernels "asm"/"group"
+    // heavy-first dispatch order of kernels "asm"/"group": TWO lists (list | 3 counters | middle-class list) used
+    // alternately, so that the pre-pass of launch L+1 (memset + classify, on the aux stream) can run while the tile
+    // kernel of launch L still reads the other list
+    uint32_t *d_order[2] = {nullptr, nullptr};
     size_t order_cap = 0;         // regions
+    unsigned order_turn = 0;
+    hipStream_t aux = nullptr;    // the pre-pass stream
+    hipEvent_t ev_cls[2] = {nullptr, nullptr};   // pre-pass into list k finished
+    hipEvent_t ev_done[2] = {nullptr, nullptr};  // the tile kernel that read list k finished
+    bool done_valid[2] = {false, false};
     WorkQueues *d_queues = nullptr;  // kernel "refill"
     mbk::ScanCursors *d_cursors = nullptr;  // kernel "scan": two sets, used alternately
     uint32_t *d_entries = nullptr;   // kernel "scan": the 64 todo lists (block ids)
@@ -137,6 +146,17 @@ static double axis_value_host(const Axis &a, uint32_t k)
     return v;
 }
 
+// Is the pinned last sample of the axis what the regular formula gives anyway, fl(fl((n-1)*step)+start) == stop?
+// (np.linspace overwrites y[n-1] with `stop`; for every DataChunk level probed -- and for cfg2's axes -- the
+// formula lands on it exactly.)  Then the blocks holding that sample need no special case in the fast paths.
+static bool axis_end_is_regular(const Axis &a)
+{
+    if (a.n <= 1 || a.step_is_zero) return false;
+    volatile double y = (double)(a.n - 1u) * a.step;
+    volatile double v = y + a.start;
+    return v == a.last;
+}
+
 // Coordinates must stay far from overflow so that no inf-inf = NaN can appear before the bailout
 // test fires (the hand-scheduled kernels compare the high word of |z|^2 as an integer).
 static const double kMaxCoord = 0x1p500;
@@ -193,7 +213,13 @@ static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling, b
 
 static void free_scratch(StreamScratch &sc)
 {
-    if (sc.d_order) (void)hipFree(sc.d_order);
+    if (sc.aux) (void)hipStreamSynchronize(sc.aux);
+    for (int k = 0; k < 2; ++k) {
+        if (sc.d_order[k]) (void)hipFree(sc.d_order[k]);
+        if (sc.ev_cls[k]) (void)hipEventDestroy(sc.ev_cls[k]);
+        if (sc.ev_done[k]) (void)hipEventDestroy(sc.ev_done[k]);
+    }
+    if (sc.aux) (void)hipStreamDestroy(sc.aux);
     if (sc.d_queues) (void)hipFree(sc.d_queues);
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
@@ -246,6 +272,8 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     const uint32_t order_mode = ctx->opt[MBK_OPT_ORDER], probe_steps = ctx->opt[MBK_OPT_PROBE_STEPS];
     a.perm_mul = order_mode == 1 ? coprime_multiplier(grid.x) : 1u;
     a.order = nullptr;
+    int order_slot = -1;
+    StreamScratch *order_sc = nullptr;
     if (order_mode == 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps && a.blocks_x <= 0xffffu && by <= 0xffffu) {
         // (a list entry packs block row and workgroup column into 16 bits each; wider windows go in image order)
         // heavy-first dispatch order (see classify_blocks_kernel); small launches skip it: one kernel in image
@@ -253,23 +281,49 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         StreamScratch *sc = nullptr;
         int rc = get_scratch(ctx, stream, &sc);
         if (rc != MBK_OK) return rc;
-        if (grid.x > sc->order_cap) {
-            // the old list may still be read by a kernel in flight on this stream
-            if (sc->d_order) {
-                MBK_HIP(ctx, hipStreamSynchronize(stream));
-                (void)hipFree(sc->d_order);
+        const bool overlap = ctx->opt[MBK_OPT_PREPASS_OVERLAP] != 0u;
+        if (!sc->aux) {
+            MBK_HIP(ctx, hipStreamCreateWithFlags(&sc->aux, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                MBK_HIP(ctx, hipEventCreateWithFlags(&sc->ev_cls[k], hipEventDisableTiming));
+                MBK_HIP(ctx, hipEventCreateWithFlags(&sc->ev_done[k], hipEventDisableTiming));
             }
-            sc->d_order = nullptr;
+        }
+        if (grid.x > sc->order_cap) {
+            // the old lists may still be read / written by kernels in flight on the two streams
+            MBK_HIP(ctx, hipStreamSynchronize(stream));
+            MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
+            for (int k = 0; k < 2; ++k) {
+                if (sc->d_order[k]) (void)hipFree(sc->d_order[k]);
+                sc->d_order[k] = nullptr;
+                sc->done_valid[k] = false;
+            }
             sc->order_cap = 0;
             // list | 3 counters | middle-class list (classify_blocks_kernel)
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_order, (2u * (size_t)grid.x + 3u) * sizeof(uint32_t)));
+            for (int k = 0; k < 2; ++k)
+                MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], (2u * (size_t)grid.x + 3u) * sizeof(uint32_t)));
             sc->order_cap = grid.x;
         }
-        uint32_t *ord = sc->d_order;
+        // Pre-pass of THIS launch on the aux stream: it depends on the window only, not on anything the caller's
+        // stream computes, so it may run while the previous launch's tile kernel is still busy (memset + classify
+        // are 13 us of a 577 us cfg2 step, with the chip nearly idle).  List k is free once the tile kernel that
+        // read it two launches ago has finished (ev_done); the tile kernel waits for its list (ev_cls).  With
+        // prepass_overlap = 0 everything goes to the caller's stream, as in rounds 1-2.
+        const unsigned k = sc->order_turn++ & 1u;
+        uint32_t *ord = sc->d_order[k];
         uint32_t *cursors = ord + grid.x;   // right behind the list: the tile kernel finds them at order[gridDim.x]
-        MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, stream, a,
+        hipStream_t pre = overlap ? sc->aux : stream;
+        if (overlap && sc->done_valid[k]) MBK_HIP(ctx, hipStreamWaitEvent(sc->aux, sc->ev_done[k], 0));
+        // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
+        MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
+        hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a,
                            grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
+        if (overlap) {
+            MBK_HIP(ctx, hipEventRecord(sc->ev_cls[k], sc->aux));
+            MBK_HIP(ctx, hipStreamWaitEvent(stream, sc->ev_cls[k], 0));
+        }
+        order_slot = (int)k;
+        order_sc = sc;
         a.order = ord;
         a.heavy_hint = sc->h_hint + 1;
     }
@@ -296,6 +350,10 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     else
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, 0, stream, a);
     MBK_HIP(ctx, hipGetLastError());
+    if (order_slot >= 0) {   // list `order_slot` is busy until this tile kernel has finished
+        MBK_HIP(ctx, hipEventRecord(order_sc->ev_done[order_slot], stream));
+        order_sc->done_valid[order_slot] = true;
+    }
     return MBK_OK;
 }
 
@@ -317,9 +375,11 @@ static void set_window_facts(TileArgs &a, bool f32)
     a.ring_possible = window_may_touch_ring(a, f32 ? 2e-3 : 1e-6) ? 1u : 0u;
     a.fast_bx_end = a.fast_by_end = 0u;
     if (a.re.step_is_zero || a.im.step_is_zero) return;
-    // window columns / rows before the axis' last sample (col0 + ncols <= n: validate_view)
-    const uint64_t cols_ok = std::min<uint64_t>(a.ncols, (uint64_t)a.re.n - 1u - std::min<uint64_t>(a.col0, (uint64_t)a.re.n - 1u));
-    const uint64_t rows_ok = std::min<uint64_t>(a.nrows, (uint64_t)a.im.n - 1u - std::min<uint64_t>(a.row0, (uint64_t)a.im.n - 1u));
+    // window columns / rows before the axis' last sample (col0 + ncols <= n: validate_view); the last sample itself
+    // counts when the regular formula reproduces it (axis_end_is_regular)
+    const uint64_t re_n = (uint64_t)a.re.n - (axis_end_is_regular(a.re) ? 0u : 1u), im_n = (uint64_t)a.im.n - (axis_end_is_regular(a.im) ? 0u : 1u);
+    const uint64_t cols_ok = std::min<uint64_t>(a.ncols, re_n - std::min<uint64_t>(a.col0, re_n));
+    const uint64_t rows_ok = std::min<uint64_t>(a.nrows, im_n - std::min<uint64_t>(a.row0, im_n));
     a.fast_bx_end = (uint32_t)(cols_ok / 8u);
     a.fast_by_end = (uint32_t)(rows_ok / 8u);
 }
@@ -390,10 +450,36 @@ static int launch_refill(mbk_ctx *ctx, const TileArgs &a, bool safe, hipStream_t
     return MBK_OK;
 }
 
+// Share of the window that the light pass of kernel "scan" would NOT finish: a 16 x 16 grid of its pixels is
+// iterated on the host for the 4 steps pass 1 runs (~1 000 steps, a few microseconds -- a launch costs more), and the
+// fraction still inside is returned.  A scheduling heuristic only (kernel choice of MBK_KERNEL_DEFAULT): plain
+// host doubles, no claim of bit-exactness, results never depend on it.
+static double window_heavy_share(const TileArgs &a)
+{
+    const uint32_t k = 16;
+    uint32_t inside = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+        const double ci = axis_value_host(a.im, a.row0 + (uint32_t)(((uint64_t)(2u * j + 1u) * a.nrows) / (2u * k)));
+        for (uint32_t i = 0; i < k; ++i) {
+            const double cr = axis_value_host(a.re, a.col0 + (uint32_t)(((uint64_t)(2u * i + 1u) * a.ncols) / (2u * k)));
+            double zr = cr, zi = ci;
+            bool in = true;
+            for (int n = 0; n < 4 && in; ++n) {
+                const double t = zr * zr - zi * zi + cr;
+                zi = 2.0 * zr * zi + ci;
+                zr = t;
+                in = zr * zr + zi * zi < 4.0;
+            }
+            inside += in ? 1u : 0u;
+        }
+    }
+    return (double)inside / (double)(k * k);
+}
+
 // Kernel "scan": a persistent light pass over every 8x8 block, then one workgroup per block it listed as
 // unfinished (mbk_scan.h).  Launches the light pass cannot serve go to launch_blocks ("group").
 template <typename T>
-static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream)
+static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream, double probe_share)
 {
     const bool f32 = sizeof(T) == 4;
     a.blocks_x = (a.ncols + 7u) / 8u;
@@ -454,7 +540,9 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     else s.col_jump = std::max(1u, a.blocks_x * 5u / 16u);
     if (s.col_jump >= a.blocks_x) s.col_jump = 0u, s.col_period = 0u;
     s.fast_bx_end = a.ncols / 8u;
-    s.fast_by_end = std::min(a.nrows / 8u, a.im.n > a.row0 + 8u ? (a.im.n - a.row0 - 1u) / 8u : 0u);
+    // block rows whose imaginary coordinates all come from the regular formula (the asm computes them that way)
+    const uint32_t im_n = a.im.n - (axis_end_is_regular(a.im) ? 0u : 1u);
+    s.fast_by_end = std::min(a.nrows / 8u, im_n > a.row0 ? (im_n - a.row0) / 8u : 0u);
     s.qtab = 0u;
     if (a.bytes && a.mrd > 0)
         for (uint32_t k = 1; k <= 4u; ++k)
@@ -462,9 +550,17 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     // pass 2: 64 lists x (hint = longest list of the previous launch on this stream + 25 %).  Never fewer
     // workgroups than fill the chip (when the tile has that many blocks): a hint from a light tile followed by
     // a heavy one would otherwise leave a few waves looping over whole lists.
+    // Round 3: when the host probe of THIS window (window_heavy_share) found no pixel that outlives the light pass,
+    // pass 2 is launched as one workgroup per CU (its stride loop keeps it correct if the probe missed a thin
+    // feature): the 8 192 workgroups of the floor above cost 4.3 us to find nothing, on a tile whose pass 1
+    // takes 23 -- and 3 tiles in 4 of a pyramid level are that tile -- whatever the previous launch listed.
     const uint32_t hint = sc->h_hint[0];
-    s.ranks2 = hint == 0xffffffffu ? qcap : (uint32_t)std::min<uint64_t>(qcap, (uint64_t)hint + hint / 4u + 2u);
-    s.ranks2 = std::max(s.ranks2, std::min(qcap, (cus * 32u + mbk::kScanQueues - 1u) / mbk::kScanQueues));
+    if (probe_share == 0.0) {
+        s.ranks2 = std::min(qcap, (cus + mbk::kScanQueues - 1u) / mbk::kScanQueues);
+    } else {
+        s.ranks2 = hint == 0xffffffffu ? qcap : (uint32_t)std::min<uint64_t>(qcap, (uint64_t)hint + hint / 4u + 2u);
+        s.ranks2 = std::max(s.ranks2, std::min(qcap, (cus * 32u + mbk::kScanQueues - 1u) / mbk::kScanQueues));
+    }
     if (s.ranks2 == 0u) s.ranks2 = 1u;
     s.hint_out = sc->h_hint;
     s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] == 16u ? 1u : 0u;
@@ -487,32 +583,6 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
         }
     }
     return MBK_OK;
-}
-
-// Share of the window that the light pass of kernel "scan" would NOT finish: a 16 x 16 grid of its pixels is
-// iterated on the host for the 4 steps pass 1 runs (~1 000 steps, a few microseconds -- a launch costs more), and the
-// fraction still inside is returned.  A scheduling heuristic only (kernel choice of MBK_KERNEL_DEFAULT): plain
-// host doubles, no claim of bit-exactness, results never depend on it.
-static double window_heavy_share(const TileArgs &a)
-{
-    const uint32_t k = 16;
-    uint32_t inside = 0;
-    for (uint32_t j = 0; j < k; ++j) {
-        const double ci = axis_value_host(a.im, a.row0 + (uint32_t)(((uint64_t)(2u * j + 1u) * a.nrows) / (2u * k)));
-        for (uint32_t i = 0; i < k; ++i) {
-            const double cr = axis_value_host(a.re, a.col0 + (uint32_t)(((uint64_t)(2u * i + 1u) * a.ncols) / (2u * k)));
-            double zr = cr, zi = ci;
-            bool in = true;
-            for (int n = 0; n < 4 && in; ++n) {
-                const double t = zr * zr - zi * zi + cr;
-                zi = 2.0 * zr * zi + ci;
-                zr = t;
-                in = zr * zr + zi * zi < 4.0;
-            }
-            inside += in ? 1u : 0u;
-        }
-    }
-    return (double)inside / (double)(k * k);
 }
 
 static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t flags,
@@ -567,13 +637,13 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
             // by its 0.27 ns per workgroup and its stores, and "scan" wins (all-exterior tile: 29 us against 71).
             // Launches under 16 k blocks take "group", which for them is a single kernel in image order (cfg1: 20
             // us, scan 24).  heavy_share = 0 forces "group", 65536 forces "scan".
-            if (kernel == MBK_KERNEL_DEFAULT) {
-                if ((uint64_t)((a.ncols + 7u) / 8u) * ((a.nrows + 7u) / 8u) < 16384u)
-                    return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
-                if (window_heavy_share(a) * 65536.0 > (double)ctx->opt[MBK_OPT_HEAVY_SHARE] || ctx->opt[MBK_OPT_HEAVY_SHARE] == 0u)
-                    return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
-            }
-            return f32 ? launch_scan_t<float>(ctx, a, safe, stream) : launch_scan_t<double>(ctx, a, safe, stream);
+            if (kernel == MBK_KERNEL_DEFAULT && (uint64_t)((a.ncols + 7u) / 8u) * ((a.nrows + 7u) / 8u) < 16384u)
+                return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+            const double share = window_heavy_share(a);
+            if (kernel == MBK_KERNEL_DEFAULT &&
+                (share * 65536.0 > (double)ctx->opt[MBK_OPT_HEAVY_SHARE] || ctx->opt[MBK_OPT_HEAVY_SHARE] == 0u))
+                return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+            return f32 ? launch_scan_t<float>(ctx, a, safe, stream, share) : launch_scan_t<double>(ctx, a, safe, stream, share);
         }
         case MBK_KERNEL_GROUP:
         case MBK_KERNEL_ASM:
@@ -707,7 +777,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
-        /* PROBE_MID */ 6u};
+        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1096,6 +1166,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_RF_WAVES: ok = value >= 1u && value <= 8u; break;
         case MBK_OPT_CYCLE_DETECT: ok = value <= 1u; break;
         case MBK_OPT_PROBE_MID: ok = value >= 2u && value <= 65537u; break;
+        case MBK_OPT_PREPASS_OVERLAP: ok = value <= 1u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");
@@ -1156,6 +1227,55 @@ int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_
     MBK_HIP(ctx, hipStreamSynchronize(s));
     std::memset(stats, 0, sizeof(*stats));
     fill_stats_from_reduce(sc->h_red, stats, false);
+    return MBK_OK;
+}
+
+// ---- the native worker loop (mbk_feeder.h) ----------------------------------------------------------------
+
+static int ctx_submit(void *user, int slot, uint32_t level, uint32_t mrd, uint32_t ir, uint32_t ii, uint8_t *h_bytes)
+{
+    return mbk_datachunk_submit_ex((mbk_ctx *)user, slot, level, mrd, ir, ii, h_bytes, nullptr, MBK_LAZY_UNIFORM);
+}
+static int ctx_wait(void *user, int slot, mbk_stats *stats) { return mbk_wait((mbk_ctx *)user, slot, stats); }
+static void *ctx_alloc(void *user, uint64_t bytes)
+{
+    void *p = nullptr;
+    return mbk_host_alloc((mbk_ctx *)user, bytes, &p) == MBK_OK ? p : nullptr;
+}
+static void ctx_release(void *user, void *ptr) { (void)mbk_host_free((mbk_ctx *)user, ptr); }
+
+int mbk_feeder_run(const mbk_feeder_ops *ops, const char *addr, uint16_t port, uint64_t max_tiles, uint32_t senders,
+                   mbk_worker_report *report)
+{
+    if (!ops || !ops->submit || !ops->wait || !ops->alloc || !ops->release || !addr)
+        return fail(nullptr, MBK_ERR_INVALID, "NULL argument");
+    std::string err;
+    const int rc = mbkf::run(ops, addr, port, max_tiles, senders, report, &err);
+    if (rc != MBK_OK) return fail(nullptr, rc, err);
+    return MBK_OK;
+}
+
+int mbk_worker_run(mbk_ctx *ctx, const char *addr, uint16_t port, uint64_t max_tiles, uint32_t senders,
+                   mbk_worker_report *report)
+{
+    if (!ctx || !addr) return fail(ctx, MBK_ERR_INVALID, "NULL argument");
+    for (Slot &sl : ctx->s)
+        if (sl.busy) return fail(ctx, MBK_ERR_INVALID, "a slot still has a tile in flight: call mbk_wait first");
+    MBK_HIP(ctx, hipSetDevice(ctx->device));
+    mbk_feeder_ops ops;
+    ops.user = ctx;
+    ops.submit = ctx_submit;
+    ops.wait = ctx_wait;
+    ops.alloc = ctx_alloc;
+    ops.release = ctx_release;
+    ops.on_tile = nullptr;
+    std::string err;
+    const int rc = mbkf::run(&ops, addr, port, max_tiles, senders, report, &err);
+    if (rc != MBK_OK) {
+        // a backend failure left its own message on the ctx; keep it, prefixed
+        const std::string inner = ctx->err;
+        return fail(ctx, rc, inner.empty() || rc == MBK_ERR_NET ? err : err + ": " + inner);
+    }
     return MBK_OK;
 }
 

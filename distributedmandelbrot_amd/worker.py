@@ -320,13 +320,46 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
     return sent_ok[0]
 
 
+def run_native(addr: str, port: int, device_index: int = 0, log: Callable[..., None] = print,
+               max_tiles: Optional[int] = None, senders: int = 4, device=None) -> int:
+    """run_pipelined's loop in native code: ONE call into libmbk_hip.so (mbk_worker_run, include/mbk.h) leases,
+    computes and sends tiles until the server answers 0x11 or `max_tiles` were leased -- same wire traffic, no
+    Python on the per-tile path (the GIL is released for the whole call; sender threads are C++ threads).
+    Returns the number of tiles sent (accepted, incl. resets); the process-wide `stats` are updated."""
+    import ctypes as C
+    from . import _lib as L
+    from .device import MandelbrotDevice, MbkError
+    own = device is None
+    dev = device if device is not None else MandelbrotDevice(device_index)
+    rep = L.mbk_worker_report()
+    try:
+        st = dev._lib.mbk_worker_run(dev._h, addr.encode(), port, max_tiles or 0, max(1, senders), C.byref(rep))
+        with _stats_lock:
+            stats["accepted"] += rep.accepted
+            stats["rejected"] += rep.rejected
+            stats["resets"] += rep.resets
+        rate = rep.leased / rep.seconds if rep.seconds > 0 else 0.0
+        log(f"native feeder: {rep.leased} tiles leased, {rep.accepted} accepted, {rep.rejected} rejected, {rep.resets} "
+            f"reset after accept, {rep.uniform_tiles} uniform (not copied off the GPU); {rep.seconds:.3f} s = {rate:.1f} "
+            f"tiles/s; kernel time {rep.kernel_ms_sum:.1f} ms; {rep.pixel_iterations / 1e9:.2f} G pixel-iterations "
+            "(reference-equivalent)")
+        if st != L.MBK_OK:
+            raise MbkError(st, (dev._lib.mbk_last_error(dev._h) or b"").decode())
+        return int(rep.accepted + rep.resets)
+    finally:
+        if own:
+            dev.close()
+
+
 def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
              make_compute: Optional[Callable[[int], ComputeFn]] = None,
-             log: Callable[..., None] = print, max_tiles: Optional[int] = None, senders: int = 2) -> List[int]:
+             log: Callable[..., None] = print, max_tiles: Optional[int] = None, senders: int = 2,
+             native: bool = False) -> List[int]:
     """One feeder thread per GPU until the Distributer answers 0x11.  Each feeder is `run_pipelined`
-    (lease / compute / send overlapped, two tiles in flight on its GPU); with `make_compute(device_index)`
-    -- a per-thread compute function, used by the CPU tests -- it is the serial do_workload_single loop.
-    Returns the number of tiles each feeder completed."""
+    (lease / compute / send overlapped, two tiles in flight on its GPU) or, with native=True, `run_native` (the
+    same loop inside libmbk_hip.so; `max_tiles` is then split evenly over the feeders up front); with
+    `make_compute(device_index)` -- a per-thread compute function, used by the CPU tests -- it is the serial
+    do_workload_single loop.  Returns the number of tiles each feeder completed."""
     if devices is None:
         from .device import device_count
         devices = list(range(device_count()))
@@ -350,6 +383,11 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
     def feeder(slot: int, dev_index: int) -> None:
         tag = lambda *a: log(f"[gpu{dev_index}]", *a)
         try:
+            if make_compute is None and native:
+                share = None if max_tiles is None else (max_tiles + len(devices) - 1 - slot) // len(devices)
+                if share is None or share > 0:
+                    done[slot] = run_native(addr, port, dev_index, log=tag, senders=senders, max_tiles=share)
+                return
             if make_compute is None:
                 done[slot] = run_pipelined(addr, port, dev_index, log=tag, senders=senders, take=take)
                 return
@@ -382,8 +420,9 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
         port = int(input("Server Port> "))
     devices = [int(x) for x in argv[2].split(",")] if len(argv) >= 3 else None
     # every listed GPU gets its own pipelined feeder (an explicit single index -- `worker ADDR PORT 3` --
-    # runs on THAT GPU; round 1 sent it to GPU 0); no list = every visible GPU, and run_farm raises when there is none
-    run_farm(addr, port, devices)
+    # runs on THAT GPU; round 1 sent it to GPU 0); no list = every visible GPU, and run_farm raises when there is none.
+    # The feeders are the native loop (mbk_worker_run); `worker ADDR PORT GPUS python` keeps the Python one.
+    run_farm(addr, port, devices, native=not (len(argv) >= 4 and argv[3] == "python"), senders=4)
     log_stats = dict(stats)
     print("tiles:", log_stats)
 

@@ -38,7 +38,8 @@ enum mbk_status {
     MBK_ERR_INVALID = 1,   /* bad argument (NULL pointer, empty window outside the view, mrd > INT32_MAX ...) */
     MBK_ERR_NO_DEVICE = 2, /* no HIP device / device index out of range / not a gfx950-class GPU */
     MBK_ERR_HIP = 3,       /* a HIP runtime call failed; see mbk_last_error */
-    MBK_ERR_NOMEM = 4
+    MBK_ERR_NOMEM = 4,
+    MBK_ERR_NET = 5        /* mbk_worker_run / mbk_feeder_run: a socket call failed or the server spoke out of protocol */
 };
 
 /* flags for the compute calls */
@@ -225,8 +226,8 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
  * range.  Defaults in brackets.
  */
 enum mbk_option {
-    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] three-class list
-                              (probe never escaped / escaped late / escaped early) */
+    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] heavy-first list
+                              (probe never escaped first; optionally a middle class, MBK_OPT_PROBE_MID) */
     MBK_OPT_WAVES_PER_WG,  /* asm/group: 8x8 blocks per workgroup: [1], 2, 4 */
     MBK_OPT_GROUP_STEPS,   /* group: steps per grouped bailout test: 4, 8, [16] (16 applies to the blocks classified as
                               interior -- probe-heavy / dense --, the rest keep 8).  Scan pass 2 and the fp32 loops have no
@@ -246,9 +247,14 @@ enum mbk_option {
                               (zr, zi) bit pattern repeats an earlier state of its own orbit -- the step map is a
                               deterministic function of those bits, so the reference's loop provably runs to mrd-1 and
                               returns 0.  Same counts, fewer executed steps on tiles that hold part of the set: 0, [1] */
-    MBK_OPT_PROBE_MID,     /* asm/group: a block whose probe pixel escapes at step >= this value goes to the middle dispatch
-                              class (after the blocks whose probe never escaped, before the rest): 2..65537 [6]; a value
-                              above probe_steps leaves the middle class empty = the two-class order of round 2 */
+    MBK_OPT_PROBE_MID,     /* asm/group: a block whose probe pixel escapes at step >= this value goes to a middle dispatch
+                              class (after the blocks whose probe never escaped, before the rest): 2..[65537]; a value
+                              above probe_steps leaves the middle class empty = the two-class order.  Measured on cfg2
+                              (profiles/r03): 6 -> 581.8 us per launch, off -> 577.8: the light blocks are dispatch-bound
+                              and must stay interleaved with the boundary blocks, so the default is off */
+    MBK_OPT_PREPASS_OVERLAP, /* asm/group: run the dispatch-order pre-pass (memset + classify, 13 us on cfg2) on an auxiliary
+                              stream, into one of two alternating lists, so that it overlaps the PREVIOUS launch's tile
+                              kernel on the caller's stream (the tile kernel waits for its list through an event): 0, [1] */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
@@ -267,6 +273,53 @@ int mbk_quantise_counts(mbk_ctx *ctx, const int32_t *h_counts, uint64_t n, uint3
  * kernel time into pixel-iterations/s from the kernel's own output. */
 int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_t mrd,
                       void *hip_stream, mbk_stats *stats);
+
+/*
+ * The worker loop in native code: lease -> compute -> send, pipelined, until the Distributer answers 0x11
+ * ("no workload available") or max_tiles (0 = no limit) have been leased.  Replaces the loop of the reference worker,
+ * WorkerCUDA.py:111-184 (do_workload_single called from main until it returns False), speaking the protocol of
+ * Distributer.cs:30-45,358-458 / DistributerWorkload.cs:53-100 UNCHANGED: per tile the wire sees exactly the
+ * reference's two exchanges (request 0x00 -> 0x10 + 4 x u32 | 0x11; response 0x01 + 4 x u32 -> 0x20 | 0x21, then on
+ * 0x20 exactly MBK_CHUNK_BYTES raw bytes); only their timing overlaps with other tiles': while tile n is on the GPU
+ * (slot n % 2, its D2H overlapping the other slot's kernel) tile n+1 is being leased and tiles <= n-1 are being sent
+ * by `senders` threads (1..64) on their own connections.  `senders + 2` pinned 16 MiB buffers circulate, so a slow
+ * server back-pressures the lease rate.  Uniform tiles (all 0 / all 1) are not copied off the GPU: their payload
+ * comes from a shared constant buffer.  A rejected tile (0x21) is dropped and the loop carries on (WorkerCUDA.py:
+ * 161-163).  On a socket error while leasing the loop stops leasing, finishes the tiles it holds, and returns
+ * MBK_ERR_NET (mbk_last_error has the text).  The same single-host-thread rule as everything else on a ctx: the
+ * calling thread drives the GPU; the sender threads touch sockets and host buffers only.
+ * distributedmandelbrot_amd/worker.py: run_native / run_farm bind it; run_pipelined is the same loop in Python.
+ */
+typedef struct mbk_worker_report {
+    uint64_t leased;           /* tiles obtained with opcode 0x00 */
+    uint64_t accepted;         /* 0x20 and every payload byte handed to the socket */
+    uint64_t rejected;         /* 0x21 */
+    uint64_t resets;           /* 0x20, then the server reset the connection mid-payload (the reference server reads the
+                                  payload with ONE Receive and closes, Distributer.cs:416-423: the tile is complete there) */
+    uint64_t uniform_tiles;    /* sent from the shared constant buffer */
+    uint64_t pixel_iterations; /* reference-equivalent, summed over the tiles */
+    double kernel_ms_sum;
+    double seconds;            /* wall time of the call */
+} mbk_worker_report;
+int mbk_worker_run(mbk_ctx *ctx, const char *addr, uint16_t port, uint64_t max_tiles, uint32_t senders,
+                   mbk_worker_report *report);
+
+/* The same protocol loop over a caller-supplied compute backend (mbk_worker_run is this with the backend bound to a
+ * GPU context: submit = mbk_datachunk_submit_ex(MBK_LAZY_UNIFORM), wait = mbk_wait, alloc/release = pinned memory).
+ * For hosts that schedule the GPU themselves, and for the CPU tests of the protocol engine.  submit / wait are
+ * called from the calling thread only, with slot alternating 0, 1; wait must fill stats (all_bytes_zero /
+ * all_bytes_one decide whether h_bytes or a constant buffer is sent).  on_tile (optional) is called from a sender
+ * thread once per returned tile with status 1 accepted, 0 rejected, 2 reset after 0x20, -1 error. */
+typedef struct mbk_feeder_ops {
+    void *user;
+    int (*submit)(void *user, int slot, uint32_t level, uint32_t mrd, uint32_t index_real, uint32_t index_imag, uint8_t *h_bytes);
+    int (*wait)(void *user, int slot, mbk_stats *stats);
+    void *(*alloc)(void *user, uint64_t bytes);
+    void (*release)(void *user, void *ptr);
+    void (*on_tile)(void *user, const uint32_t workload[4], const mbk_stats *stats, int status);
+} mbk_feeder_ops;
+int mbk_feeder_run(const mbk_feeder_ops *ops, const char *addr, uint16_t port, uint64_t max_tiles, uint32_t senders,
+                   mbk_worker_report *report);
 
 #ifdef __cplusplus
 }

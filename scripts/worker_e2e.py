@@ -1,6 +1,6 @@
 """End-to-end tile rate of the drop-in worker against the threaded stand-in Distributer (loopback TCP):
 the reference's serial loop (do_workload_single) vs the pipelined feeder (run_pipelined: lease / compute / send
-overlapped, two tiles in flight on the GPU).  Run on the GPU box:
+overlapped, two tiles in flight on the GPU) vs the same loop in native code (run_native = mbk_worker_run).  Run on the GPU box:
     python scripts/worker_e2e.py [level] [mrd] [senders]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -53,4 +53,11 @@ for s in sorted({1, 2, senders}):
         assert done == n and settle(dist, n)
         dt = time.perf_counter() - t0
     print(f"pipelined worker, {s} sender thread(s): {n / dt:.1f} tiles/s ({dt / n * 1e3:.2f} ms/tile); stats {dict(worker.stats)}")
+for s in sorted({2, 4, 8, senders}):
+    with Distributer([(level, mrd)]) as dist:
+        t0 = time.perf_counter()
+        done = worker.run_native("127.0.0.1", dist.port, device=dev, log=QUIET, senders=s)
+        assert done == n and settle(dist, n)
+        dt = time.perf_counter() - t0
+    print(f"native feeder (mbk_worker_run), {s} sender thread(s): {n / dt:.1f} tiles/s ({dt / n * 1e3:.2f} ms/tile)")
 dev.close()

@@ -253,3 +253,203 @@ def test_pipelined_worker_sends_constant_payload_for_uniform_tiles():
             assert n == 4 and srv.wait_completed(4) and dev.lazy == 4
             for data in srv.completed.values():
                 assert data.size == CHUNK_BYTES and (data == value).all()
+
+
+# ------------------------------------------------------------------------------------------------------
+# Round 3: the same loop in native code (mbk_feeder_run in libmbk_hip.so; mbk_worker_run binds it to a GPU).
+# The protocol engine is driven here through a backend made of ctypes callbacks: the compute is a pattern
+# (or the oracle) -- the product binding, mbk_worker_run, needs a GPU and is covered by the -m gpu tests.
+# ------------------------------------------------------------------------------------------------------
+
+class _NativeBackend:
+    """mbk_feeder_ops over Python callbacks: two slots, pattern compute, optional uniform tiles."""
+
+    def __init__(self, compute=pattern_compute, uniform_value=None, fail_submit_at=None):
+        import ctypes as C
+        from distributedmandelbrot_amd import _lib as L
+        self.C, self.L = C, L
+        self.compute, self.uniform_value, self.fail_submit_at = compute, uniform_value, fail_submit_at
+        self.pending = [None, None]
+        self.submitted, self.tiles, self.max_inflight, self.slots = [], [], 0, []
+        self._bufs = {}
+        self.ops = L.mbk_feeder_ops(None, L.FEEDER_SUBMIT(self._submit), L.FEEDER_WAIT(self._wait),
+                                    L.FEEDER_ALLOC(self._alloc), L.FEEDER_RELEASE(self._release),
+                                    L.FEEDER_ON_TILE(self._on_tile))
+
+    def _alloc(self, user, n):
+        buf = (self.C.c_uint8 * n)()
+        addr = self.C.addressof(buf)
+        self._bufs[addr] = buf
+        return addr
+
+    def _release(self, user, ptr):
+        self._bufs.pop(ptr, None)
+
+    def _submit(self, user, slot, level, mrd, ir, ii, h_bytes):
+        if self.fail_submit_at is not None and len(self.submitted) == self.fail_submit_at:
+            return 1
+        assert self.pending[slot] is None, "slot reused before wait"
+        self.pending[slot] = ((level, mrd, ir, ii), h_bytes)
+        self.submitted.append((level, mrd, ir, ii))
+        self.slots.append(slot)
+        self.max_inflight = max(self.max_inflight, sum(p is not None for p in self.pending))
+        return 0
+
+    def _wait(self, user, slot, stats):
+        w, ptr = self.pending[slot]
+        self.pending[slot] = None
+        st = stats.contents
+        st.kernel_ms, st.d2h_ms, st.pixel_iterations, st.never_pixels = 0.5, 0.1, 1000, 0
+        st.all_bytes_zero = st.all_bytes_one = 0
+        st.rle_runs = 0
+        if self.uniform_value is None:
+            np.ctypeslib.as_array((self.C.c_uint8 * CHUNK_BYTES).from_address(ptr))[:] = self.compute(*w)
+        else:   # MBK_LAZY_UNIFORM: the buffer is left untouched, the stats carry the constant
+            st.all_bytes_zero, st.all_bytes_one = int(self.uniform_value == 0), int(self.uniform_value == 1)
+        return 0
+
+    def _on_tile(self, user, w, stats, status):
+        self.tiles.append((tuple(w.contents), status))
+
+    def run(self, port, max_tiles=0, senders=2, addr="127.0.0.1"):
+        lib = self.L.load()
+        rep = self.L.mbk_worker_report()
+        rc = lib.mbk_feeder_run(self.C.byref(self.ops), addr.encode(), port, max_tiles, senders, self.C.byref(rep))
+        return rc, rep, (lib.mbk_last_error(None) or b"").decode()
+
+
+def test_native_feeder_same_wire_every_tile_once():
+    """mbk_feeder_run against the restated Distributer: per tile the reference's two exchanges
+    (WorkerCUDA.py:115-134,148-172), every tile completed exactly once with the backend's bytes, both slots used,
+    and the loop ends on 0x11 like the reference worker (WorkerCUDA.py:127-129)."""
+    with FakeDistributer([(3, 16), (1, 8)]) as srv:
+        be = _NativeBackend()
+        rc, rep, err = be.run(srv.port, senders=3)
+        assert rc == 0, err
+        assert srv.wait_completed(10)
+        assert (rep.leased, rep.accepted, rep.rejected, rep.resets, rep.uniform_tiles) == (10, 10, 0, 0, 0)
+        assert rep.pixel_iterations == 10 * 1000 and rep.seconds > 0
+        assert sorted(be.submitted) == sorted(srv.completed) and len(set(be.submitted)) == 10
+        assert be.max_inflight == 2 and be.slots[:4] == [0, 1, 0, 1]
+        assert sorted(be.tiles) == sorted((w, 1) for w in srv.completed)
+        for w, data in srv.completed.items():
+            assert np.array_equal(data, pattern_compute(*w))
+        assert not [l for l in srv.log if "error" in l or "unknown" in l], srv.log
+        assert not be._bufs                                  # every result buffer was released
+
+
+def test_native_feeder_max_tiles_threaded_server_and_oracle_bytes(oracle, golden):
+    import hashlib
+    from distributedmandelbrot_amd.server import Distributer
+
+    def settled(dist, k):
+        import time
+        for _ in range(1000):
+            if dist.received == k:
+                return True
+            time.sleep(0.01)
+        return False
+
+    with Distributer([(4, 16)]) as dist:
+        rc, rep, err = _NativeBackend().run(dist.port, max_tiles=7, senders=4)
+        assert rc == 0 and rep.leased == 7 and rep.accepted == 7 and settled(dist, 7), err
+        rc, rep, err = _NativeBackend().run(dist.port)
+        assert rc == 0 and rep.leased == 9 and settled(dist, 16) and dist.all_done(), err
+    # one real tile through the native loop: the bytes that arrive are the reference's (golden SHA-256)
+    with FakeDistributer([(1, 256)]) as srv:
+        be = _NativeBackend(compute=lambda l, m, ir, ii: oracle.datachunk(l, m, ir, ii, want_counts=False)[1].ravel())
+        rc, rep, err = be.run(srv.port)
+        assert rc == 0 and rep.accepted == 1 and srv.wait_completed(1), err
+        assert hashlib.sha256(srv.completed[(1, 256, 0, 0)].tobytes()).hexdigest() == str(golden["full/1_256_0_0/bytes_sha256"])
+
+
+def test_native_feeder_uniform_tiles_rejects_and_errors():
+    # uniform tiles: the wire still carries 16 777 216 bytes of the constant, from a shared buffer
+    for value in (0, 1):
+        with FakeDistributer([(2, 16)]) as srv:
+            be = _NativeBackend(uniform_value=value)
+            rc, rep, err = be.run(srv.port)
+            assert rc == 0 and rep.uniform_tiles == 4 and srv.wait_completed(4), err
+            for data in srv.completed.values():
+                assert data.size == CHUNK_BYTES and (data == value).all()
+    # a result whose lease expired meanwhile is rejected (0x21): dropped, the loop carries on (WorkerCUDA.py:161-163)
+    with FakeDistributer([(1, 8)]) as srv:
+        be = _NativeBackend()
+        orig = be._wait
+
+        def wait_and_expire(user, slot, stats):
+            srv.expire_all_leases()
+            return orig(user, slot, stats)
+        be.ops.wait = be.L.FEEDER_WAIT(wait_and_expire)
+        rc, rep, err = be.run(srv.port, max_tiles=1)
+        assert rc == 0 and rep.leased == 1 and rep.rejected == 1 and rep.accepted == 0, err
+        assert be.tiles == [((1, 8, 0, 0), 0)] and srv.rejected == [(1, 8, 0, 0)]
+    # nobody listening: MBK_ERR_NET with the reason, not a hang and not a silent zero
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        dead_port = s_.getsockname()[1]
+    rc, rep, err = _NativeBackend().run(dead_port)
+    assert rc == 5 and "connect" in err and rep.leased == 0
+    # a server that speaks out of protocol (WorkerCUDA.py:131-132 raises on an unknown reply)
+    srv_sock = socket.socket()
+    srv_sock.bind(("127.0.0.1", 0))
+    srv_sock.listen(1)
+
+    def bad_server():
+        c, _ = srv_sock.accept()
+        c.recv(1)
+        c.sendall(bytes([0x77]))
+        c.close()
+    th = threading.Thread(target=bad_server, daemon=True)
+    th.start()
+    rc, rep, err = _NativeBackend().run(srv_sock.getsockname()[1])
+    th.join(timeout=5)
+    srv_sock.close()
+    assert rc == 5 and "Unknown response code to request: 119" in err
+    # a backend failure while tiles are in flight: the tiles already computed still arrive, the status is the backend's
+    with FakeDistributer([(2, 16)]) as srv:
+        be = _NativeBackend(fail_submit_at=2)
+        rc, rep, err = be.run(srv.port)
+        assert rc == 1 and "backend submit failed" in err and rep.accepted == 2 and srv.wait_completed(2)
+
+
+def test_native_feeder_against_the_single_receive_server():
+    """The reference server reads the payload with ONE Receive and closes (Distributer.cs:416-423): the still-sending
+    client may be reset although the tile is complete on the server.  Counted as a reset, not an error."""
+    with FakeDistributer([(1, 8)], faithful_single_receive=True) as srv:
+        rc, rep, err = _NativeBackend().run(srv.port)
+        assert rc == 0 and rep.leased == 1 and rep.accepted + rep.resets == 1 and srv.wait_completed(1), err
+
+
+def test_run_farm_refuses_an_empty_device_list(monkeypatch):
+    """`worker ADDR PORT` on a box without a visible GPU must raise, not print 'tiles: 0' and exit 0."""
+    from distributedmandelbrot_amd import device
+    monkeypatch.setattr(device, "device_count", lambda: 0)
+    with pytest.raises(RuntimeError, match="no gfx950 GPU visible"):
+        worker.main(["127.0.0.1", "1"])
+    with pytest.raises(RuntimeError, match="no gfx950 GPU visible"):
+        worker.run_farm("127.0.0.1", 1, devices=[])
+
+
+def test_pipelined_worker_drains_inflight_tiles_when_the_lease_connection_fails():
+    """an exception from request_workload must not drop the tiles already on the device: they are waited
+    for and sent, the device's slots end up free, and the error is re-raised afterwards."""
+    calls = {"n": 0}
+    real = worker.request_workload
+
+    def flaky(addr, port, timeout=None):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise ConnectionRefusedError("server restarting")
+        return real(addr, port, timeout)
+
+    with FakeDistributer([(2, 16)]) as srv:
+        dev = _FakeDevice()
+        worker.request_workload = flaky
+        try:
+            with pytest.raises(ConnectionRefusedError):
+                worker.run_pipelined("127.0.0.1", srv.port, device=dev, log=QUIET, senders=2)
+        finally:
+            worker.request_workload = real
+        assert srv.wait_completed(2) and len(dev.submitted) == 2
+        assert all(p is None for p in dev.slots)
