@@ -565,7 +565,7 @@ def main():
         if rank == 0:
             cursor.reset(0)
         barrier()
-    if not fake and args.ramp_ms > 0 and own_mode:   # clock pre-conditioning (untimed, see --ramp-ms)
+    if not fake and args.ramp_ms > 0:   # clock pre-conditioning (untimed, see --ramp-ms): every rank, its own GPU
         t_ramp = time.perf_counter()
         while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
             launch_own(0)
@@ -694,7 +694,7 @@ def main():
                "never_escaped_pixels": never, "parallelism": f"{world} independent work queue(s), no collective"
                if own_mode else f"{world} rank(s) pulling from one shared cursor, no collective",
                "streams_per_gpu": nstreams, "shard": args.shard, "control_backend": backend,
-               "clock_ramp_ms": args.ramp_ms if (own_mode and not fake) else 0.0,
+               "clock_ramp_ms": args.ramp_ms if not fake else 0.0,
                "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz,
                "cycle_leg_error": cyc_err,
                "occupancy_api_wg_per_cu": device_info.get("scan_occupancy"),

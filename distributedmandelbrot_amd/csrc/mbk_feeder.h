@@ -105,8 +105,9 @@ static int connect_to(const char *addr, uint16_t port, std::string *err)
         if (err->empty()) *err = "connect: no usable address";
         return -1;
     }
-    const int one = 1;
+    const int one = 1, sndbuf = 4 << 20;   // a 16 MiB payload follows: fewer, larger sends
     (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+    (void)setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &sndbuf, sizeof(sndbuf));
     return fd;
 }
 

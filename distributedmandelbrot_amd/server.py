@@ -31,8 +31,9 @@ DEFAULT_DISTRIBUTER_PORT = 59010  # Program.cs:13
 DEFAULT_DATA_SERVER_PORT = 59011  # Program.cs:14
 
 
-def _recv_exact(c: socket.socket, n: int) -> bytearray:
-    buf = bytearray(n)
+def _recv_exact(c: socket.socket, n: int, buf: Optional[bytearray] = None) -> bytearray:
+    if buf is None:
+        buf = bytearray(n)
     view, got = memoryview(buf), 0
     while got < n:
         k = c.recv_into(view[got:], n - got)
@@ -106,7 +107,22 @@ class Distributer(_TcpLoop):
         self.completed = set(store.completed()) if store is not None else set()
         self.rejected: List[Workload] = []
         self.received = 0
+        # Payload buffers are recycled: a fresh bytearray(16 MiB) per tile is a 16 MiB zero-fill plus 4 096 page
+        # faults, ~2 ms -- more than the GPU needs for most tiles.  A store that keeps a payload must copy it
+        # (ChunkStore.save_chunk writes it out before returning).
+        self._pool: List[bytearray] = []
         super().__init__(host, port)
+
+    def _take_buffer(self) -> bytearray:
+        with self._state:
+            if self._pool:
+                return self._pool.pop()
+        return bytearray(CHUNK_BYTES)
+
+    def _give_buffer(self, buf: bytearray) -> None:
+        with self._state:
+            if len(self._pool) < 16:
+                self._pool.append(buf)
 
     def _next_needed(self) -> Optional[Workload]:
         now = time.monotonic()
@@ -150,9 +166,11 @@ class Distributer(_TcpLoop):
                 self.rejected.append(w)
                 c.sendall(bytes([0x21]))
                 return
+            raw = self._take_buffer()
             try:
+                c.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 4 << 20)   # fewer, larger receives
                 c.sendall(bytes([0x20]))
-                payload = np.frombuffer(_recv_exact(c, CHUNK_BYTES), dtype=np.uint8)
+                payload = np.frombuffer(_recv_exact(c, CHUNK_BYTES, raw), dtype=np.uint8)
             except BaseException:
                 with self._state:       # the tile did not arrive: the lease is live again
                     self.receiving.pop(w, None)
@@ -163,6 +181,8 @@ class Distributer(_TcpLoop):
                 self.completed.add((w[0], w[2], w[3]))
             if self.store is not None:  # the reference saves on a thread-pool task (Distributer.cs:436-442)
                 self.store.save_chunk(w[0], w[2], w[3], payload)
+            del payload
+            self._give_buffer(raw)
             with self._state:
                 self.received += 1      # counts tiles that are accepted AND stored
         else:

@@ -774,14 +774,13 @@ def test_prepass_overlap_transitions_and_regrowth(oracle):
     want = [oracle.view(v.start_r, v.start_i, v.range_r, v.range_i, v.width, v.height, m, want_bytes=False)[0] for v, m in views]
     with MandelbrotDevice(0) as dev:
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        outs = []
-        for rep in range(12):
-            i = (rep * 5 + rep // 3) % len(views)
+        plan = [(rep * 5 + rep // 3) % len(views) for rep in range(12)]
+        outs = [(i, torch.full((views[i][0].width * views[i][0].height,), -3, dtype=torch.int32, device="cuda:0")) for i in plan]
+        torch.cuda.synchronize()      # the fills ran on torch's current stream; the launches below go to other streams
+        for rep, (i, o) in enumerate(outs):
             v, m = views[i]
             dev.set_option("prepass_overlap", 0 if rep in (4, 5, 9) else 1)
-            o = torch.full((v.width * v.height,), -3, dtype=torch.int32, device="cuda:0")
             dev.launch_view(v, m, d_counts=o.data_ptr(), stream=streams[rep % 2].cuda_stream, kernel="group")
-            outs.append((i, o))
         torch.cuda.synchronize()
         for i, o in outs:
             v, _ = views[i]
