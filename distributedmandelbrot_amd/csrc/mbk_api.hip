@@ -615,6 +615,7 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     a.quant_rcp = mrd ? 1.0 / (double)mrd : 0.0;
     a.perm_mul = 1u;
     a.exact_steps = ctx->opt[MBK_OPT_EXACT_STEPS];
+    a.exact_steps_long = std::min(ctx->opt[MBK_OPT_EXACT_STEPS], ctx->opt[MBK_OPT_EXACT_LONG]);
     a.order = nullptr;
     a.counts = wc ? d_counts : nullptr;
     a.bytes = wb ? d_bytes : nullptr;
@@ -777,7 +778,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
-        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u};
+        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 8u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1167,6 +1168,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_CYCLE_DETECT: ok = value <= 1u; break;
         case MBK_OPT_PROBE_MID: ok = value >= 2u && value <= 65537u; break;
         case MBK_OPT_PREPASS_OVERLAP: ok = value <= 1u; break;
+        case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

@@ -45,6 +45,7 @@ struct TileArgs {
     uint32_t quant_wide;  // 1: count*256+mrd-1 does not fit 32 bits -> 64-bit quantiser division
     double quant_rcp;     // fl(1/mrd), host-computed: the narrow quantiser divides by multiplying (see quantise)
     uint32_t exact_steps; // steps tested one by one before the grouped test takes over
+    uint32_t exact_steps_long;  // the same for the blocks that run 16-step groups (classified as interior)
     uint32_t ring_possible;  // 0 = the host proved that no pixel of the window lies near |c| = 2
     uint32_t fast_bx_end, fast_by_end;  // 8x8 blocks with column index < fast_bx_end and row index < fast_by_end
                           // lie wholly inside the window, hold neither axis' pinned last sample, and both steps
@@ -226,7 +227,9 @@ __device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint
         } else if (kGroup == 16) {
             // 16-step groups (6.125 issue slots per step) only where the test hardly ever trips (interior of
             // the set: the blocks a probe or the light pass classified as such); 8 elsewhere
-            count = long_groups ? escape_count_group<16, kCycle>(cr, ci, p.mrd, &m, p.exact_steps)
+            // (blocks classified as interior skip the per-step prologue when MBK_OPT_EXACT_LONG says so: with the
+            // deferred replay a lane that does escape early costs one trip + the block's single fix-up)
+            count = long_groups ? escape_count_group<16, kCycle>(cr, ci, p.mrd, &m, p.exact_steps_long)
                                 : escape_count_group<8, kCycle>(cr, ci, p.mrd, &m, p.exact_steps);
         } else {
             count = escape_count_group<kGroup == 8 ? 8 : 4, kCycle>(cr, ci, p.mrd, &m, p.exact_steps);

@@ -255,6 +255,8 @@ enum mbk_option {
     MBK_OPT_PREPASS_OVERLAP, /* asm/group: run the dispatch-order pre-pass (memset + classify, 13 us on cfg2) on an auxiliary
                               stream, into one of two alternating lists, so that it overlaps the PREVIOUS launch's tile
                               kernel on the caller's stream (the tile kernel waits for its list through an event): 0, [1] */
+    MBK_OPT_EXACT_LONG,    /* group / scan pass 2: cap on exact_steps for the blocks that run 16-step groups (classified as
+                              interior, where hardly any lane escapes early): 0..4096 [8 = no cap] */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

@@ -60,4 +60,19 @@ for s in sorted({2, 4, 8, senders}):
         assert done == n and settle(dist, n)
         dt = time.perf_counter() - t0
     print(f"native feeder (mbk_worker_run), {s} sender thread(s): {n / dt:.1f} tiles/s ({dt / n * 1e3:.2f} ms/tile)")
+# ... and against a native sink (scripts/sink_distributer.cpp: same protocol, one C++ thread per connection, payload
+# read and dropped): what the feeder sustains when the server is not the bottleneck
+import os, subprocess, tempfile
+exe = os.path.join(tempfile.gettempdir(), "mbk_sink_distributer")
+subprocess.check_call(["g++", "-O2", "-pthread", "-o", exe, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sink_distributer.cpp")])
+for s in sorted({4, 8, 16, senders}):
+    srv = subprocess.Popen([exe, str(level), str(mrd)], stdout=subprocess.PIPE, text=True)
+    port = int(srv.stdout.readline().split()[1])
+    t0 = time.perf_counter()
+    done = worker.run_native("127.0.0.1", port, device=dev, log=QUIET, senders=s)
+    line = srv.stdout.readline().strip()
+    dt = time.perf_counter() - t0
+    srv.wait(timeout=10)
+    assert done == n and line.startswith(f"DONE {n} "), (done, line)
+    print(f"native feeder -> native sink, {s} sender thread(s): {n / dt:.1f} tiles/s ({dt / n * 1e3:.2f} ms/tile)")
 dev.close()

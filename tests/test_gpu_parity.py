@@ -403,6 +403,7 @@ OPTION_MATRIX = [
     ("group", {"probe_mid": 2}), ("group", {"probe_mid": 65537, "cycle_detect": 0}), ("default", {"probe_mid": 20, "probe_steps": 64}),
     ("default", {"heavy_share": 0}), ("default", {"heavy_share": 65536}),
     ("group", {"prepass_overlap": 0}), ("default", {"prepass_overlap": 0, "probe_mid": 6}),
+    ("group", {"exact_long": 0}), ("scan", {"exact_long": 0, "cycle_detect": 0}), ("default", {"exact_long": 3, "exact_steps": 5}),
 ]
 
 
