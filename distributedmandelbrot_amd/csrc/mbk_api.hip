@@ -778,7 +778,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
-        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 8u};
+        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \

@@ -256,7 +256,8 @@ enum mbk_option {
                               stream, into one of two alternating lists, so that it overlaps the PREVIOUS launch's tile
                               kernel on the caller's stream (the tile kernel waits for its list through an event): 0, [1] */
     MBK_OPT_EXACT_LONG,    /* group / scan pass 2: cap on exact_steps for the blocks that run 16-step groups (classified as
-                              interior, where hardly any lane escapes early): 0..4096 [8 = no cap] */
+                              interior, where hardly any lane escapes early -- and one that does costs a trip plus the
+                              block's single fix-up): [0] = no per-step prologue for them .. 4096 (cfg2 +0.4 %, inset +0.5 %) */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
