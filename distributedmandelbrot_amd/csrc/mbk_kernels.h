@@ -196,10 +196,12 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
 // also ruled out the |c| = 2 ring for the whole window the per-wave ring test goes too (~20 of the ~57 VALU
 // instructions a block costs outside its loop; on cfg2 that overhead is 15 M of 317 M instructions).
 // kCycle: the grouped loops retire exactly periodic orbits early (mbk_loops.inc, MBK_G_CYC).
+// (ucol, urow): the block's first column / row inside the window, wave-uniform; (lx, ly): this lane's pixel in the block.
 template <typename T, bool kFmaDouble, int kGroup, bool kCycle = false>
-__device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint32_t lr, bool long_groups,
-                                            bool interior = false)
+__device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t ucol, uint32_t urow, uint32_t lx, uint32_t ly,
+                                            bool long_groups, bool interior = false)
 {
+    const uint32_t lc = ucol + lx, lr = urow + ly;
     T cr, ci;
     bool ring_test = kGroup != 0 && kFmaDouble;
     if (interior) {
@@ -220,7 +222,8 @@ __device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint
         if (ring_test) {
             const T c2 = cr * cr + ci * ci;
             const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
-            risky = __any(c2 > (T)4 - margin && c2 < (T)4 + margin) != 0;
+            // (c2 - 4 is exact near 4 -- Sterbenz --, so this is the band 4 +- margin in two instructions)
+            risky = __ballot(__builtin_fabs((double)(c2 - (T)4)) < (double)margin) != 0ull;
         }
         if (risky) {
             count = escape_count_asm<true>(cr, ci, p.mrd, &m);
@@ -237,10 +240,13 @@ __device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t lc, uint
     } else {
         count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd, &m);
     }
-    const size_t o = (size_t)(lr + p.out_row0) * p.out_pitch + lc + p.out_col0;
-    if (p.counts) p.counts[o] = count;
-    if (p.bytes) p.bytes[o] = quantise(count, p);
-    if (p.smooth) p.smooth[o] = smooth_value(count, (double)m);
+    // output element = scalar base of the block (64-bit, on the scalar unit) + a 32-bit lane offset: ly * pitch < 2^31
+    // because the window has more than ly rows and at most 2^31 pixels (validate_view)
+    const size_t ubase = (size_t)(urow + p.out_row0) * p.out_pitch + ucol + p.out_col0;
+    const uint32_t loff = ly * p.out_pitch + lx;
+    if (p.counts) (p.counts + ubase)[loff] = count;
+    if (p.bytes) (p.bytes + ubase)[loff] = quantise(count, p);
+    if (p.smooth) (p.smooth + ubase)[loff] = smooth_value(count, (double)m);
 }
 
 // Kernels "asm" (kGroup = 0) and "group": one 8x8 block per wave, blockDim / 64 blocks per workgroup.
@@ -271,12 +277,10 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
         bx = blk - by * p.blocks_x;
     }
     const uint32_t wcol = bx * (blockDim.x >> 6) + wave;  // one 8x8 block per wave
-    const uint32_t lc = wcol * 8u + (lane & 7u);
-    const uint32_t lr = by * 8u + (lane >> 3);
     // the blocks the heavy-first probe put at the front of the dispatch order take the 16-step groups
     const bool long_groups = kGroup == 16 && (!p.order || blockIdx.x < n_heavy);   // wave-uniform
     const bool interior = wcol < p.fast_bx_end && by < p.fast_by_end;                        // wave-uniform
-    block_pixel<T, kFmaDouble, kGroup, kCycle>(p, lc, lr, long_groups, interior);
+    block_pixel<T, kFmaDouble, kGroup, kCycle>(p, wcol * 8u, by * 8u, lane & 7u, lane >> 3, long_groups, interior);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void tile_todo_kernel(TileArgs p, ScanArgs s)
         const uint32_t blk = uniform_u32(s.entries[q * s.qcap + (i < len_d ? i : s.qcap - 1u - (i - len_d))]);
         const uint32_t by = blk / p.blocks_x, bx = blk - by * p.blocks_x;
         // dense blocks (interior): 16-step groups, 6.125 slots per step; the others: 8 (cheaper replays)
-        block_pixel<T, true, 16, kCycle>(p, bx * 8u + lx, by * 8u + ly, s.long_groups != 0u && i < len_d,
+        block_pixel<T, true, 16, kCycle>(p, bx * 8u, by * 8u, lx, ly, s.long_groups != 0u && i < len_d,
                                          bx < p.fast_bx_end && by < p.fast_by_end);
     }
 }

@@ -14,7 +14,7 @@ for f in sorted(glob.glob(os.path.join(src, "*_kernel_stats.csv"))):
 for f in sorted(glob.glob(os.path.join(src, "power_*.json"))):
     shutil.copy(f, dst)
 for extra in ("rocminfo.txt", "nproc.txt", "valu_rates.log", "level16.log", "worker_e2e.log", "cfg2_default_pmc_by_kernel.json", "soak.log",
-              "pytest_gpu.log"):
+              "pytest_gpu.log", "cfg3_group_pmc.json", "cfg3_refill_pmc.json", "source_sha256.txt", "smoke.log"):
     p = os.path.join(src, extra)
     if os.path.exists(p):
         out = extra.replace("valu_rates.log", "valu_rates_microbench.txt").replace("soak.log", "soak.txt").replace("pytest_gpu.log", "pytest_gpu.txt")
@@ -30,6 +30,12 @@ if os.path.exists(by):
               key=lambda k: d[k].get("SQ_INSTS_VALU", {}).get("mean", 0), default=None)
     if dom:
         out = {"kernel": dom}
+        # the sources the counters were collected on: bench.py quotes `traffic` only while they match the tree
+        sha = os.path.join(src, "source_sha256.txt")
+        if os.path.exists(sha):
+            out["source_sha256"] = open(sha).read().split()[-1]
+        out["note"] = ("vgpr_as_reported is rocprofv3's VGPR_Count = (granulated count + 1) x 4, i.e. half of the 48 registers "
+                       "allocated for the 42 the ISA uses (gfx950 allocates in granules of 8)")
         out.update(d[dom])
         json.dump(out, open(os.path.join(dst, "cfg2_default_pmc_summary.json"), "w"), indent=1)
 print(sorted(os.listdir(dst)))
