@@ -107,7 +107,7 @@ DEFAULT_STEPS = {"cfg1": (400, 50), "cfg2": (400, 50), "chunk_l1": (400, 50), "i
                  "cfg3": (20, 3), "cfg4": (3, 1), "cfg5": (40, 5)}
 # CPU baseline sample: every `stride`-th 8-row band, sized for ~10-30 CPU-seconds on >= 64 host threads
 CPU_SAMPLE_STRIDE = {"cfg4": 256}
-PMC_SUMMARIES = [("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
+PMC_SUMMARIES = [("r03", "cfg2_default_pmc_summary.json"), ("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
 
 
 def parse_args(argv=None):
@@ -760,7 +760,8 @@ def main():
                 "speedup_vs_strict": elapsed_max / cyc_leg[0],
                 "same_pixel_iterations_and_never_count": bool(cyc_leg[1]),
             }
-        if world == 1 and own_mode and not fake and not args.no_extras and args.workload == "cfg2" and not smooth:
+        if (world == 1 and own_mode and not fake and not args.no_extras and args.workload == "cfg2" and not smooth
+                and args.precision == "f64" and args.kernel == "default" and not options):
             # beside the headline (never in `value`): the end-to-end tile rate, and the N > 1 default job on this GPU
             try:   # the same strict steps with TWO launches in flight (two streams): what a two-slot worker context does
                 s2 = torch.cuda.Stream()

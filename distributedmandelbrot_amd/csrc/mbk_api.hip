@@ -325,7 +325,8 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         order_slot = (int)k;
         order_sc = sc;
         a.order = ord;
-        a.heavy_hint = sc->h_hint + 1;
+        a.ngrid = grid.x;
+        a.order_mid = ctx->opt[MBK_OPT_PROBE_MID] <= probe_steps ? 1u : 0u;
     }
     if (f32 && safe)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, 0, stream, a);

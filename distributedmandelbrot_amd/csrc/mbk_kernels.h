@@ -54,8 +54,8 @@ struct TileArgs {
     const uint32_t *order; // optional dispatch order (three-class list from classify_blocks_kernel, whose comment has
                            // the layout); an entry is (block row << 16) | workgroup column -- the host offers it only
                            // when both fit 16 bits
-    uint32_t *heavy_hint;  // optional, pinned host memory: with `order`, workgroup 0 reports the share of
-                           // probe-heavy regions (x 65536) -- next launch's kernel choice (mbk_api.hip)
+    uint32_t ngrid;        // with `order`: the grid size (= list length); the counters sit at order[ngrid .. ngrid + 3)
+    uint32_t order_mid;    // with `order`: 1 = a middle class was built (MBK_OPT_PROBE_MID <= probe depth)
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
     double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value
@@ -260,17 +260,23 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     uint32_t bx, by;
     uint32_t n_heavy = 0u;
     if (p.order) {
-        // three classes (classify_blocks_kernel): heavy at the front of the list, light filled in from its back,
-        // and the middle class in a list of its own right behind the three counters
-        n_heavy = p.order[gridDim.x];
-        const uint32_t n_mid = p.order[gridDim.x + 2u];
+        // classes (classify_blocks_kernel): heavy at the front of the list, light filled in from its back, and -- only
+        // when a middle class was built (p.order_mid) -- that class in a list of its own right behind the three
+        // counters.  Without it a wave needs ONE load for its entry, issued together with the heavy count: the grid
+        // size comes with the arguments (p.ngrid), not from the dispatch packet, so a wave's start is two scalar
+        // round trips (arguments, then entry + count) instead of four -- a light block lives for little else.
         const uint32_t j = blockIdx.x;
-        const uint32_t e = (j >= n_heavy && j < n_heavy + n_mid) ? p.order[gridDim.x + 3u + (j - n_heavy)]
-                                                                 : p.order[j];   // packed: no division here
+        uint32_t e;
+        if (p.order_mid) {
+            n_heavy = p.order[p.ngrid];
+            const uint32_t n_mid = p.order[p.ngrid + 2u];
+            e = (j >= n_heavy && j < n_heavy + n_mid) ? p.order[p.ngrid + 3u + (j - n_heavy)] : p.order[j];
+        } else {
+            e = p.order[j];   // packed: no division here
+            n_heavy = p.order[p.ngrid];
+        }
         by = e >> 16;
         bx = e & 0xffffu;
-        if (p.heavy_hint && blockIdx.x == 0 && threadIdx.x == 0)
-            *p.heavy_hint = (uint32_t)(((uint64_t)n_heavy << 16) / gridDim.x);
     } else {
         const uint32_t blk = (uint32_t)(((uint64_t)blockIdx.x * p.perm_mul) % gridDim.x);
         by = blk / p.blocks_x;
