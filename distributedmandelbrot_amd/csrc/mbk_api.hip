@@ -85,6 +85,7 @@ struct mbk_ctx {
     size_t rle_cap_px = 0;
     uint32_t opt[MBK_OPT_COUNT_];    // tuning options (mbk_set_option); every value is bit-exact
     int scan_occ[2][2] = {{0, 0}, {0, 0}};  // resident single-wave workgroups per CU: [f64|f32][scan|heavy]
+    int scan_occ_inline[2] = {0, 0};        // the same for pass 1 in its finish-in-place form (MBK_OPT_SCAN_INLINE)
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -491,15 +492,61 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     // round of a statically strided pass would double its time) -- what the occupancy query reports for the
     // kernel, capped by the scan_waves option -- rounded down to whole block rows.
     const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-    const uint32_t per_cu = std::min<uint32_t>(4u * ctx->opt[MBK_OPT_SCAN_WAVES], (uint32_t)ctx->scan_occ[f32 ? 1 : 0][0]);
+    // Nothing of the window's probe grid outlives the light pass (probe_share == 0: an all-exterior tile): pass 1
+    // finishes its own leftovers and there is no pass 2 (tile_light_kernel, kInline)
+    const bool inline_todo = probe_share == 0.0 && ctx->opt[MBK_OPT_SCAN_INLINE] != 0u;
+    const uint32_t per_cu = std::min<uint32_t>(4u * ctx->opt[MBK_OPT_SCAN_WAVES],
+                                               (uint32_t)(inline_todo ? ctx->scan_occ_inline[f32 ? 1 : 0] : ctx->scan_occ[f32 ? 1 : 0][0]));
     const uint32_t wmax = cus * per_cu;
     if (safe || a.re.step_is_zero || a.im.step_is_zero || a.smooth != nullptr || (a.bytes && a.quant_wide) ||
         total_steps < 4u || !(a.counts || a.bytes) || a.blocks_x > wmax)
         return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
 
     mbk::ScanArgs s;
+    std::memset(&s, 0, sizeof(s));
     s.stride_by = std::min(wmax / a.blocks_x, nby);
+    // (pass 1 addresses a run of blocks through a 32-bit lane offset that advances by this much per block)
+    if ((uint64_t)s.stride_by * 8u * a.out_pitch * 4u >= (1ull << 31)) return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
     const uint32_t w1 = s.stride_by * a.blocks_x;
+    s.nblocks = nblocks;
+    // XCD-aware column order (profiles/microbench/light_path.hip: the 8x8 store pattern of a 4096^2 int32 tile
+    // takes 25.6 us in image order -- each 128-byte line is written by four XCDs -- and 12.9 us with it)
+    s.xcd_map = (ctx->opt[MBK_OPT_SCAN_XCD_MAP] != 0u && a.blocks_x % 32u == 0u) ? 1u : 0u;
+    // column jump: ~5/16 of the width, a multiple of 32 columns when the XCD map is on (keeps its grouping).  It
+    // spreads the unfinished blocks of a window over the lists; where nothing is expected to be unfinished (the
+    // finish-in-place form) a wave keeps its column: the jumps cost the all-exterior tile 3 of its 23 us
+    // (profiles/r03/light_path_ab.txt).
+    s.col_period = inline_todo ? 0u : ctx->opt[MBK_OPT_SCAN_COL_PERIOD];
+    if (s.xcd_map) s.col_jump = 32u * (((a.blocks_x / 32u) * 5u / 16u) | 1u);
+    else s.col_jump = std::max(1u, a.blocks_x * 5u / 16u);
+    if (s.col_jump >= a.blocks_x) s.col_jump = 0u, s.col_period = 0u;
+    s.fast_bx_end = a.ncols / 8u;
+    // block rows whose imaginary coordinates all come from the regular formula (the asm computes them that way)
+    const uint32_t im_n = a.im.n - (axis_end_is_regular(a.im) ? 0u : 1u);
+    s.fast_by_end = std::min(a.nrows / 8u, im_n > a.row0 ? (im_n - a.row0) / 8u : 0u);
+    s.qtab = 0u;
+    if (a.bytes && a.mrd > 0)
+        for (uint32_t k = 1; k <= 4u; ++k)
+            s.qtab |= (uint32_t)(((uint64_t)k * 256u + (uint32_t)a.mrd - 1u) / (uint32_t)a.mrd & 0xffu) << (8u * (k - 1u));
+    s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] == 16u ? 1u : 0u;
+    set_window_facts(a, f32);
+#define MBK_LAUNCH_LIGHT(INL)                                                                                              \
+    do {                                                                                                                   \
+        if (a.counts && a.bytes)                                                                                           \
+            hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, true, INL>), dim3(w1), dim3(64), 0, stream, a, s);         \
+        else if (a.bytes)                                                                                                  \
+            hipLaunchKernelGGL((mbk::tile_light_kernel<T, false, true, INL>), dim3(w1), dim3(64), 0, stream, a, s);        \
+        else                                                                                                               \
+            hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, false, INL>), dim3(w1), dim3(64), 0, stream, a, s);        \
+    } while (0)
+    if (inline_todo) {
+        // one launch, no lists, no scratch: a block the light path cannot finish is finished where it is found
+        if (ctx->opt[MBK_OPT_CYCLE_DETECT] != 0u) MBK_LAUNCH_LIGHT(2);
+        else MBK_LAUNCH_LIGHT(1);
+        MBK_HIP(ctx, hipGetLastError());
+        return MBK_OK;
+    }
+
     // every list is fed by the waves with its index mod 64; a wave lists at most its own blocks
     const uint32_t qcap = ((w1 + mbk::kScanQueues - 1u) / mbk::kScanQueues) * ((nby + s.stride_by - 1u) / s.stride_by);
     StreamScratch *sc = nullptr;
@@ -531,30 +578,12 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     ++sc->scan_turn;
     s.entries = sc->d_entries;
     s.qcap = qcap;
-    s.nblocks = nblocks;
-    // XCD-aware column order (profiles/microbench/light_path.hip: the 8x8 store pattern of a 4096^2 int32 tile
-    // takes 25.6 us in image order -- each 128-byte line is written by four XCDs -- and 12.9 us with it)
-    s.xcd_map = (ctx->opt[MBK_OPT_SCAN_XCD_MAP] != 0u && a.blocks_x % 32u == 0u) ? 1u : 0u;
-    // column jump: ~5/16 of the width, a multiple of 32 columns when the XCD map is on (keeps its grouping)
-    s.col_period = ctx->opt[MBK_OPT_SCAN_COL_PERIOD];
-    if (s.xcd_map) s.col_jump = 32u * (((a.blocks_x / 32u) * 5u / 16u) | 1u);
-    else s.col_jump = std::max(1u, a.blocks_x * 5u / 16u);
-    if (s.col_jump >= a.blocks_x) s.col_jump = 0u, s.col_period = 0u;
-    s.fast_bx_end = a.ncols / 8u;
-    // block rows whose imaginary coordinates all come from the regular formula (the asm computes them that way)
-    const uint32_t im_n = a.im.n - (axis_end_is_regular(a.im) ? 0u : 1u);
-    s.fast_by_end = std::min(a.nrows / 8u, im_n > a.row0 ? (im_n - a.row0) / 8u : 0u);
-    s.qtab = 0u;
-    if (a.bytes && a.mrd > 0)
-        for (uint32_t k = 1; k <= 4u; ++k)
-            s.qtab |= (uint32_t)(((uint64_t)k * 256u + (uint32_t)a.mrd - 1u) / (uint32_t)a.mrd & 0xffu) << (8u * (k - 1u));
     // pass 2: 64 lists x (hint = longest list of the previous launch on this stream + 25 %).  Never fewer
     // workgroups than fill the chip (when the tile has that many blocks): a hint from a light tile followed by
     // a heavy one would otherwise leave a few waves looping over whole lists.
-    // Round 3: when the host probe of THIS window (window_heavy_share) found no pixel that outlives the light pass,
-    // pass 2 is launched as one workgroup per CU (its stride loop keeps it correct if the probe missed a thin
-    // feature): the 8 192 workgroups of the floor above cost 4.3 us to find nothing, on a tile whose pass 1
-    // takes 23 -- and 3 tiles in 4 of a pyramid level are that tile -- whatever the previous launch listed.
+    // When the host probe of THIS window (window_heavy_share) found no pixel that outlives the light pass and the
+    // finish-in-place form is switched off, pass 2 is launched as one workgroup per CU (its stride loop keeps it correct
+    // if the probe missed a thin feature) instead of the chip-filling floor.
     const uint32_t hint = sc->h_hint[0];
     if (probe_share == 0.0) {
         s.ranks2 = std::min(qcap, (cus + mbk::kScanQueues - 1u) / mbk::kScanQueues);
@@ -564,14 +593,8 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     }
     if (s.ranks2 == 0u) s.ranks2 = 1u;
     s.hint_out = sc->h_hint;
-    s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] == 16u ? 1u : 0u;
-    set_window_facts(a, f32);
-    if (a.counts && a.bytes)
-        hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, true>), dim3(w1), dim3(64), 0, stream, a, s);
-    else if (a.bytes)
-        hipLaunchKernelGGL((mbk::tile_light_kernel<T, false, true>), dim3(w1), dim3(64), 0, stream, a, s);
-    else
-        hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, false>), dim3(w1), dim3(64), 0, stream, a, s);
+    MBK_LAUNCH_LIGHT(0);
+#undef MBK_LAUNCH_LIGHT
     if (ctx->opt[MBK_OPT_CYCLE_DETECT] != 0u)
         hipLaunchKernelGGL((mbk::tile_todo_kernel<T, true>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
     else
@@ -779,7 +802,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
-        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u};
+        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -816,6 +839,12 @@ int mbk_create(int device, mbk_ctx **out)
                 MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fns[f][k], 64, 0));
                 ctx->scan_occ[f][k] = n > 0 ? n : 1;
             }
+        const void *fi[2] = {(const void *)mbk::tile_light_kernel<double, true, true, 2>, (const void *)mbk::tile_light_kernel<float, true, true, 2>};
+        for (int f = 0; f < 2; ++f) {
+            int n = 0;
+            MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fi[f], 64, 0));
+            ctx->scan_occ_inline[f] = n > 0 ? n : 1;
+        }
     }
 #undef MBK_CREATE_HIP
     *out = ctx;
@@ -1170,6 +1199,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_PROBE_MID: ok = value >= 2u && value <= 65537u; break;
         case MBK_OPT_PREPASS_OVERLAP: ok = value <= 1u; break;
         case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
+        case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

@@ -110,14 +110,40 @@ __device__ __forceinline__ void scan_flush(const ScanArgs &s, uint32_t q, uint32
     if (lane < n) s.entries[q * s.qcap + (dense ? idx0 + lane : s.qcap - 1u - (idx0 + lane))] = staged;
 }
 
+// Put block id b on this wave's list (dense ones apart): stage it; flush a full staging register.
+template <bool kEnabled>
+__device__ __forceinline__ void scan_list(const ScanArgs &s, uint32_t q, uint32_t b, bool dense, uint32_t &staged_d, uint32_t &nd,
+                                          uint32_t &staged_s, uint32_t &ns, uint32_t lane)
+{
+    if (!kEnabled) return;
+    if (dense) {
+        scan_stage(staged_d, b, nd);
+        if (++nd == 64u) {
+            scan_flush(s, q, staged_d, nd, true, lane);
+            nd = 0u;
+        }
+    } else {
+        scan_stage(staged_s, b, ns);
+        if (++ns == 64u) {
+            scan_flush(s, q, staged_s, ns, false, lane);
+            ns = 0u;
+        }
+    }
+}
+
 // kCounts / kBytes: which outputs the light path stores (the host picks the instantiation that matches the
 // pointers in TileArgs).  Launches that the light path cannot serve at all (smooth output, 64-bit quantiser,
 // fewer than 4 steps, windows narrower than the chip) do not come here: the host sends them to "group".
-template <typename T, bool kCounts, bool kBytes>
+// kInline (round 3): 0 = unfinished blocks go to the todo lists (pass 2 follows).  1 / 2 = the wave finishes an
+// unfinished block itself, on the spot, with the code of kernel "group" (block_pixel; 2 = with the cycle test), and NO
+// pass 2 is launched: for windows in which the host probe found nothing that outlives the light pass (3 tiles in 4 of a
+// pyramid level), where the second launch cost 4.4 us to find empty lists behind a pass 1 of 20.  Correct whatever the
+// probe missed -- a block is computed by the same two routines either way -- only slower if it missed much.
+template <typename T, bool kCounts, bool kBytes, int kInline = 0>
 __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
 {
     const uint32_t lane = threadIdx.x;
-    if (blockIdx.x == 0) {  // clear the next launch's cursors
+    if (kInline == 0 && blockIdx.x == 0) {  // clear the next launch's cursors
         unsigned int *w = reinterpret_cast<unsigned int *>(s.cur_next);
         for (uint32_t k = lane; k < (uint32_t)(sizeof(ScanCursors) / 4u); k += 64u) w[k] = 0u;
     }
@@ -128,73 +154,70 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
         bx = ((a >> 2) << 5) | (c << 2) | (a & 3u);
     }
     const uint32_t lx = lane & 7u, ly = lane >> 3;
-    const uint32_t lane_elem = ly * p.out_pitch + lx;    // constant per-lane offset of the stores
-    T cr = (T)axis_value(p.re, p.col0 + bx * 8u + lx);
-    T a0 = cr * cr;
     uint32_t sweeps_here = 0;
     uint32_t staged_d = 0, staged_s = 0, nd = 0, ns = 0;  // staged ids (lane k = k-th id) and their numbers
     const uint32_t nby = (p.nrows + 7u) / 8u;
+    // per block of a run: the row advances by rowinc, the lane's store offset by einc (bytes of the int32 output
+    // when there is one, elements otherwise: escape_light_run)
+    const uint32_t rowinc = s.stride_by * 8u;
+    const uint32_t oscale = kCounts ? 4u : 1u;
+    const uint32_t einc = rowinc * p.out_pitch * oscale;          // < 2^31 (checked by the host: launch_scan_t)
+    const uint32_t run_cap = (0xffffffffu - (7u * p.out_pitch + 7u) * oscale) / einc;   // offsets stay below 2^32
     while (by < nby) {
-        uint32_t todo = 0u;   // 0 finished, 1 some lane still inside, 2 not attempted / near the ring
-        bool dense = false;
         if (bx < s.fast_bx_end && by < s.fast_by_end) {
-            // tight loop over this wave's consecutive light blocks: the bases advance by a constant
+            // the run of this wave's consecutive light blocks: same column, stride_by block rows apart, up to the end
+            // of the regular rows, of the column period, or of what a 32-bit offset spans -- or up to the first block
+            // that four steps do not finish.  Everything the run needs is set up here, per run (nothing of it is live
+            // across the unfinished block's treatment below, which in the finish-in-place form is the whole heavy
+            // loop: its registers, not the sum of both, decide the occupancy).
+            uint32_t nrun = (s.fast_by_end - by + s.stride_by - 1u) / s.stride_by;
+            if (s.col_period != 0u) nrun = nrun < s.col_period - sweeps_here ? nrun : s.col_period - sweeps_here;
+            nrun = nrun < run_cap ? nrun : run_cap;
             const size_t elem0 = (size_t)(by * 8u + p.out_row0) * p.out_pitch + bx * 8u + p.out_col0;
-            int32_t *cptr = kCounts ? p.counts + elem0 : nullptr;
-            uint8_t *bptr = kBytes ? p.bytes + elem0 : nullptr;
-            const size_t einc = (size_t)s.stride_by * 8u * p.out_pitch;
-            T ci, zr, zi, a, bq;
+            // (the bases are wave-uniform; saying so explicitly keeps them in SGPRs, which the asm needs)
+            int32_t *cb = reinterpret_cast<int32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(kCounts ? p.counts + elem0 : nullptr)));
+            uint8_t *bb = reinterpret_cast<uint8_t *>(uniform_u64(reinterpret_cast<unsigned long long>(kBytes ? p.bytes + elem0 : nullptr)));
+            const T cr = (T)axis_value(p.re, p.col0 + bx * 8u + lx);   // (a block column inside fast_bx_end: regular samples)
+            const T a0 = cr * cr;
+            uint32_t row = p.row0 + by * 8u + ly, off = (ly * p.out_pitch + lx) * oscale, n = nrun;
             int32_t cnt;
-            for (;;) {
-                const uint32_t row = p.row0 + by * 8u + ly;
-                // (the bases are wave-uniform; saying so explicitly keeps them in SGPRs, which the asm needs)
-                int32_t *cb = reinterpret_cast<int32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(cptr)));
-                uint8_t *bb = reinterpret_cast<uint8_t *>(uniform_u64(reinterpret_cast<unsigned long long>(bptr)));
-                todo = p.ring_possible   // wave-uniform
-                           ? escape_light_block<kCounts, kBytes, true>(cr, a0, row, p.im.step, p.im.start, ci, zr, zi, a, bq, cnt,
-                                                                       cb, lane_elem * 4u, bb, lane_elem, s.qtab)
-                           : escape_light_block<kCounts, kBytes, false>(cr, a0, row, p.im.step, p.im.start, ci, zr, zi, a, bq, cnt,
-                                                                        cb, lane_elem * 4u, bb, lane_elem, s.qtab);
-                if (todo != 0u) break;
-                const uint32_t by_next = by + s.stride_by;
-                if ((s.col_period != 0u && sweeps_here + 1u == s.col_period) || by_next >= s.fast_by_end) break;
-                by = by_next;
+            const uint32_t unfinished = escape_light_run<kCounts, kBytes>(cr, a0, row, rowinc, p.im.step, p.im.start, cnt, cb, bb,
+                                                                          off, einc, s.qtab, n);
+            by += (nrun - n) * s.stride_by;
+            sweeps_here += nrun - n;
+            if (unfinished != 0u) {
+                // the block at `by`: some lane is still inside after 4 steps (dense: all of them)
+                const bool dense = __ballot(cnt == 5) == ~0ull;
+                if (kInline != 0) {
+                    block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, s.long_groups != 0u && dense,
+                                                           bx < p.fast_bx_end && by < p.fast_by_end);
+                } else {
+                    scan_list<kInline == 0>(s, q, by * p.blocks_x + bx, dense, staged_d, nd, staged_s, ns, lane);
+                }
+                by += s.stride_by;
                 ++sweeps_here;
-                if (kCounts) cptr += einc;
-                if (kBytes) bptr += einc;
             }
-            dense = todo == 1u && __ballot(cnt == 5) == ~0ull;
         } else {
-            todo = 2u;
-        }
-        if (todo != 0u) {   // wave-uniform: stage the block id; flush a full register
-            const uint32_t b = by * p.blocks_x + bx;
-            if (dense) {
-                scan_stage(staged_d, b, nd);
-                if (++nd == 64u) {
-                    scan_flush(s, q, staged_d, nd, true, lane);
-                    nd = 0u;
-                }
+            // not attempted: a ragged edge or the axis' pinned end point
+            if (kInline != 0) {
+                block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, false, bx < p.fast_bx_end && by < p.fast_by_end);
             } else {
-                scan_stage(staged_s, b, ns);
-                if (++ns == 64u) {
-                    scan_flush(s, q, staged_s, ns, false, lane);
-                    ns = 0u;
-                }
+                scan_list<kInline == 0>(s, q, by * p.blocks_x + bx, false, staged_d, nd, staged_s, ns, lane);
             }
+            by += s.stride_by;
+            ++sweeps_here;
         }
         // next block of this wave: same column, stride_by rows down -- except every col_period sweeps
-        by += s.stride_by;
-        if (s.col_period != 0u && ++sweeps_here >= s.col_period) {
+        if (s.col_period != 0u && sweeps_here >= s.col_period) {
             sweeps_here = 0u;
             bx += s.col_jump;
             if (bx >= p.blocks_x) bx -= p.blocks_x;
-            cr = (T)axis_value(p.re, p.col0 + bx * 8u + lx);
-            a0 = cr * cr;
         }
     }
-    if (nd != 0u) scan_flush(s, q, staged_d, nd, true, lane);
-    if (ns != 0u) scan_flush(s, q, staged_s, ns, false, lane);
+    if (kInline == 0) {
+        if (nd != 0u) scan_flush(s, q, staged_d, nd, true, lane);
+        if (ns != 0u) scan_flush(s, q, staged_s, ns, false, lane);
+    }
 }
 
 template <typename T, bool kCycle = false>

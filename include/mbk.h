@@ -258,6 +258,10 @@ enum mbk_option {
     MBK_OPT_EXACT_LONG,    /* group / scan pass 2: cap on exact_steps for the blocks that run 16-step groups (classified as
                               interior, where hardly any lane escapes early -- and one that does costs a trip plus the
                               block's single fix-up): [0] = no per-step prologue for them .. 4096 (cfg2 +0.4 %, inset +0.5 %) */
+    MBK_OPT_SCAN_INLINE,   /* scan: when the host's probe of the window finds no pixel that outlives the light pass (an
+                              all-exterior tile: 3 in 4 of a pyramid level), pass 1 finishes whatever blocks it cannot
+                              finish in 4 steps itself, on the spot, stays in its block column, and pass 2 is not launched
+                              (it cost 4.4 us to find empty lists): 0, [1] */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

@@ -5,7 +5,9 @@
 //   store8x8  the stores only, same 8x8 pattern (8 row segments of 32 B per wave instruction)
 //   store8x8x same, XCD-aware column order (a 128-byte line is completed by one XCD)
 //   store64x1 the stores only, 64 consecutive pixels per wave instruction (one 256-byte run)
-//   both      compute + store8x8 (= the product's light path)
+//   both      compute + store8x8 (round 2's light path)
+//   both_x    compute + store8x8x (= the product's light path since the XCD-aware order)
+//   strip_c / strip   the same asm on 64x1 rows (lane = column, 8 rows per 64x8 region): arithmetic only / with stores
 // Build & run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/light_path profiles/microbench/light_path.hip && /tmp/light_path
 #include "distributedmandelbrot_amd/csrc/mbk_refill.h"  // mbk_kernels.h + the wave-uniform helpers
@@ -15,7 +17,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-enum Mode { COMPUTE, STORE8, STORE8X, STORE64, BOTH };
+enum Mode { COMPUTE, STORE8, STORE8X, STORE64, BOTH, BOTHX, STRIP, STRIPC };
 
 template <int MODE>
 __global__ __launch_bounds__(64) void light_kernel(int32_t *out, double start, double step, uint32_t stride_by, uint32_t nby,
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(64) void light_kernel(int32_t *out, double start, d
     const uint32_t lane = threadIdx.x, lx = lane & 7u, ly = lane >> 3;
     const uint32_t blocks_x = 512u, pitch = 4096u;
     uint32_t by = blockIdx.x / blocks_x, bx = blockIdx.x - by * blocks_x;
-    if (MODE == STORE8X) {
+    if (MODE == STORE8X || MODE == BOTHX) {
         const uint32_t a = bx >> 3, c = bx & 7u;
         bx = ((a >> 2) << 5) | (c << 2) | (a & 3u);
     }
@@ -36,6 +38,46 @@ __global__ __launch_bounds__(64) void light_kernel(int32_t *out, double start, d
         for (; run < 64u * 4096u; run += gridDim.x * 0u + 7168u) out[(size_t)run * 64u + lane] = (int32_t)lane;
         return;
     }
+    if (MODE == STRIP || MODE == STRIPC) {
+        // 64x1 strips: lane = column, one image row per trip (ci wave-uniform), 8 rows = one 64x8 region; wave w takes
+        // regions w, w + W, ... (W a multiple of 64: a wave keeps its 64 columns).  Same asm, same arithmetic per pixel;
+        // every store instruction writes one 256-byte run.
+        const uint32_t rx = blockIdx.x & 63u;
+        const double crs = (double)(rx * 64u + lane) * step + start, a0s = crs * crs;
+        for (uint32_t band = blockIdx.x >> 6; band < 512u; band += 7168u / 64u) {
+            for (uint32_t r = 0; r < 8u; ++r) {
+                const uint32_t row = band * 8u + r;
+                double ci, zr, zi, a, b;
+                int32_t cnt;
+                int32_t *rb = out + (size_t)row * pitch + rx * 64u;
+                int32_t *cb = reinterpret_cast<int32_t *>(mbk::uniform_u64(reinterpret_cast<unsigned long long>(rb)));
+                if (MODE == STRIP) {
+                    uint32_t rowv = row, off = lane * 4u, n = 1u;
+                    mbk::escape_light_run<true, false>(crs, a0s, rowv, 1u, step, start, cnt, cb, nullptr, off, 0u, 0u, n);
+                } else {
+                    ci = (double)row * step + start;
+                    zr = crs; zi = ci; a = a0s; b = ci * ci;
+                    mbk::escape_steps_prologue4(crs, ci, zr, zi, a, b, cnt);
+                }
+                acc += cnt;
+            }
+        }
+        if (acc == 0x7fffffff) *sink = acc;
+        return;
+    }
+    if (MODE == BOTH || MODE == BOTHX) {   // the product's form: ONE asm loop over the wave's whole run of blocks
+        int32_t *base = out + (size_t)(by * 8u) * pitch + bx * 8u;
+        int32_t *cb = reinterpret_cast<int32_t *>(mbk::uniform_u64(reinterpret_cast<unsigned long long>(base)));
+        uint32_t row = by * 8u + ly, off = lane_elem * 4u, n = mbk::uniform_u32((nby - by + stride_by - 1u) / stride_by);
+        int32_t cnt;
+        uint32_t more = n;
+        while (more != 0u) {   // (an unfinished block is skipped here; loop shape as in tile_light_kernel)
+            more = mbk::escape_light_run<true, false>(cr, a0, row, stride_by * 8u, step, start, cnt, cb, nullptr, off, stride_by * 8u * pitch * 4u, 0u, n);
+            row += stride_by * 8u; off += stride_by * 8u * pitch * 4u; --n;
+            more = more != 0u ? n : 0u;
+        }
+        return;
+    }
     for (; by < nby; by += stride_by) {
         int32_t *base = out + (size_t)(by * 8u) * pitch + bx * 8u;
         if (MODE == STORE8 || MODE == STORE8X) {
@@ -44,10 +86,7 @@ __global__ __launch_bounds__(64) void light_kernel(int32_t *out, double start, d
             double ci, zr, zi, a, b;
             int32_t cnt;
             int32_t *cb = reinterpret_cast<int32_t *>(mbk::uniform_u64(reinterpret_cast<unsigned long long>(base)));
-            if (MODE == BOTH) {
-                mbk::escape_light_block<true, false, true>(cr, a0, by * 8u + ly, step, start, ci, zr, zi, a, b, cnt, cb, lane_elem * 4u,
-                                                           nullptr, lane_elem, 0u);
-            } else {   // arithmetic only: the plain prologue on the same coordinates
+            {   // arithmetic only: the plain prologue on the same coordinates
                 ci = (double)(by * 8u + ly) * step + start;
                 zr = cr; zi = ci; a = a0; b = ci * ci;
                 mbk::escape_steps_prologue4(cr, ci, zr, zi, a, b, cnt);
@@ -84,5 +123,8 @@ int main()
     run<STORE8X>("store8x8x", d_out, d_sink);
     run<STORE64>("store64x1", d_out, d_sink);
     run<BOTH>("both", d_out, d_sink);
+    run<BOTHX>("both_x", d_out, d_sink);      // compute + store8x8x: what the product's pass 1 does per block
+    run<STRIPC>("strip_c", d_out, d_sink);    // 64x1 rows: the arithmetic only
+    run<STRIP>("strip", d_out, d_sink);       // 64x1 rows: compute + one 256-byte run per store instruction
     return 0;
 }

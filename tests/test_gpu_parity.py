@@ -404,6 +404,7 @@ OPTION_MATRIX = [
     ("default", {"heavy_share": 0}), ("default", {"heavy_share": 65536}),
     ("group", {"prepass_overlap": 0}), ("default", {"prepass_overlap": 0, "probe_mid": 6}),
     ("group", {"exact_long": 0}), ("scan", {"exact_long": 0, "cycle_detect": 0}), ("default", {"exact_long": 3, "exact_steps": 5}),
+    ("scan", {"scan_inline": 0}), ("default", {"scan_inline": 0, "cycle_detect": 0}), ("scan", {"scan_inline": 1, "scan_waves": 2, "cycle_detect": 0}),
 ]
 
 
@@ -839,3 +840,36 @@ def test_native_worker_loop_on_gpu(gpu, golden):
     assert hashlib.sha256(ref.tobytes()).hexdigest() == got[(ir, ii)][2]
     with pytest.raises(Exception):
         worker.run_native("127.0.0.1", 1, device=gpu, log=lambda *a: None)   # nobody listens on port 1: MBK_ERR_NET
+
+
+# Windows whose 16 x 16 host probe sees nothing that outlives the light pass although they hold part of the set: the
+# antenna along the real axis (y = 0 lies midway between two probe rows, 0.1 away, where every pixel escapes at step 3)
+# with its minibrots; the same in a window with ragged edges and pinned end points; a far-exterior ragged window.
+NEEDLE_VIEWS = [
+    (View(-2.1, -1.6, 0.3, 3.2, 1024, 2049), 500),
+    (View(-2.1, -1.6, 0.3, 3.2, 515, 1031), 300),
+    (View(-2.0, -2.0, 1.0, 1.0, 1001, 1003), 200),
+]
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_scan_finishes_in_place_what_the_probe_missed(oracle, precision):
+    """MBK_OPT_SCAN_INLINE (round 3): when the host probe of a window finds no pixel that outlives the light pass, pass 1
+    of "scan" finishes its unfinished blocks itself and pass 2 is not launched.  The probe is a heuristic: these windows
+    hold hundreds of in-set blocks it does not see (and edge blocks, which never take the light path).  Bit-exact for
+    every output set, with and without the cycle test, and identical to the two-pass form."""
+    from distributedmandelbrot_amd import MandelbrotDevice
+    for inline, cyc in ((1, 1), (1, 0), (0, 1)):
+        with MandelbrotDevice(0) as dev:
+            dev.set_option("scan_inline", inline)
+            dev.set_option("cycle_detect", cyc)
+            for view, mrd in NEEDLE_VIEWS:
+                oc, ob, total = _oracle_view_memo(oracle, view, mrd, precision)
+                assert view.width == 1001 or int((oc == 0).sum()) > 300      # the antenna windows do hold part of the set
+                for kernel in ("scan", "default"):
+                    c, b, st = dev.compute_view(view, mrd, kernel=kernel, precision=precision)
+                    assert np.array_equal(c, oc), (view, mrd, kernel, precision, inline, cyc, int((c != oc).sum()))
+                    assert np.array_equal(b, ob) and st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum())
+                _, b2, _ = dev.compute_view(view, mrd, kernel="scan", precision=precision, want_counts=False)
+                c3, _, _ = dev.compute_view(view, mrd, kernel="scan", precision=precision, want_bytes=False)
+                assert np.array_equal(b2, ob) and np.array_equal(c3, oc)
