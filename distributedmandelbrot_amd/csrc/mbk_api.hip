@@ -481,7 +481,11 @@ static double window_heavy_share(const TileArgs &a)
 // Kernel "scan": a persistent light pass over every 8x8 block, then one workgroup per block it listed as
 // unfinished (mbk_scan.h).  Launches the light pass cannot serve go to launch_blocks ("group").
 template <typename T>
-static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream, double probe_share)
+// fuse: partial-result slots (already zeroed on `stream`) to which the finish-in-place form adds the tile's
+// pixel-iterations and never-escaped count itself; *fused says whether it did.  counts_unwanted: the int32 counts in
+// `a` exist for the statistics only -- a launch that fuses them does not write them.
+static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream, double probe_share,
+                         ReduceSlot *fuse = nullptr, bool counts_unwanted = false, bool *fused = nullptr)
 {
     const bool f32 = sizeof(T) == 4;
     a.blocks_x = (a.ncols + 7u) / 8u;
@@ -541,6 +545,25 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     } while (0)
     if (inline_todo) {
         // one launch, no lists, no scratch: a block the light path cannot finish is finished where it is found
+        if (fuse && (a.bytes || !counts_unwanted)) {
+            a.stats = fuse;
+            if (counts_unwanted) a.counts = nullptr;
+#define MBK_LAUNCH_LIGHT_STATS(INL)                                                                                        \
+    do {                                                                                                                   \
+        if (a.counts && a.bytes)                                                                                           \
+            hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, true, INL, true>), dim3(w1), dim3(64), 0, stream, a, s);   \
+        else if (a.bytes)                                                                                                  \
+            hipLaunchKernelGGL((mbk::tile_light_kernel<T, false, true, INL, true>), dim3(w1), dim3(64), 0, stream, a, s);  \
+        else                                                                                                               \
+            hipLaunchKernelGGL((mbk::tile_light_kernel<T, true, false, INL, true>), dim3(w1), dim3(64), 0, stream, a, s);  \
+    } while (0)
+            if (ctx->opt[MBK_OPT_CYCLE_DETECT] != 0u) MBK_LAUNCH_LIGHT_STATS(2);
+            else MBK_LAUNCH_LIGHT_STATS(1);
+#undef MBK_LAUNCH_LIGHT_STATS
+            MBK_HIP(ctx, hipGetLastError());
+            if (fused) *fused = true;
+            return MBK_OK;
+        }
         if (ctx->opt[MBK_OPT_CYCLE_DETECT] != 0u) MBK_LAUNCH_LIGHT(2);
         else MBK_LAUNCH_LIGHT(1);
         MBK_HIP(ctx, hipGetLastError());
@@ -610,8 +633,10 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
 }
 
 static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t flags,
-                       int32_t *d_counts, uint8_t *d_bytes, hipStream_t stream, double *d_smooth = nullptr)
+                       int32_t *d_counts, uint8_t *d_bytes, hipStream_t stream, double *d_smooth = nullptr,
+                       ReduceSlot *fuse = nullptr, bool counts_unwanted = false, bool *fused = nullptr)
 {
+    if (fused) *fused = false;
     bool safe = false;
     const bool f32 = (flags & MBK_PRECISION_F32) != 0;
     int rc = validate_view(ctx, v, &safe, f32);
@@ -668,7 +693,8 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
             if (kernel == MBK_KERNEL_DEFAULT &&
                 (share * 65536.0 > (double)ctx->opt[MBK_OPT_HEAVY_SHARE] || ctx->opt[MBK_OPT_HEAVY_SHARE] == 0u))
                 return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
-            return f32 ? launch_scan_t<float>(ctx, a, safe, stream, share) : launch_scan_t<double>(ctx, a, safe, stream, share);
+            return f32 ? launch_scan_t<float>(ctx, a, safe, stream, share, fuse, counts_unwanted, fused)
+                       : launch_scan_t<double>(ctx, a, safe, stream, share, fuse, counts_unwanted, fused);
         }
         case MBK_KERNEL_GROUP:
         case MBK_KERNEL_ASM:
@@ -703,10 +729,16 @@ static int ensure_buffers(mbk_ctx *ctx, Slot &sl, size_t px)
     return MBK_OK;
 }
 
+// clear = false: the partial results were zeroed earlier on this stream and a tile kernel has already added its fused
+// share (pixel-iterations, never-escaped count); this pass then reads the bytes only.
 static int launch_reduce(mbk_ctx *ctx, ReduceSlot *d_red, ReduceSlot *h_red, const int32_t *d_counts, const uint8_t *d_bytes,
-                         uint64_t n, uint32_t mrd, hipStream_t stream)
+                         uint64_t n, uint32_t mrd, hipStream_t stream, bool clear = true)
 {
-    MBK_HIP(ctx, hipMemsetAsync(d_red, 0, sizeof(ReduceSlot) * mbk::kReduceSlots, stream));
+    if (clear) MBK_HIP(ctx, hipMemsetAsync(d_red, 0, sizeof(ReduceSlot) * mbk::kReduceSlots, stream));
+    if (!d_counts && !d_bytes) {   // everything was fused into the tile kernel
+        MBK_HIP(ctx, hipMemcpyAsync(h_red, d_red, sizeof(ReduceSlot) * mbk::kReduceSlots, hipMemcpyDeviceToHost, stream));
+        return MBK_OK;
+    }
     const bool vec = n >= 1024u && ((uintptr_t)d_counts & 15u) == 0u && ((uintptr_t)d_bytes & 3u) == 0u;
     uint64_t blocks = ((vec ? n / 4u : n) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -729,9 +761,9 @@ static int launch_reduce(mbk_ctx *ctx, ReduceSlot *d_red, ReduceSlot *h_red, con
     return MBK_OK;
 }
 static int launch_reduce(mbk_ctx *ctx, Slot &sl, const int32_t *d_counts, const uint8_t *d_bytes, uint64_t n,
-                         uint32_t mrd, hipStream_t stream)
+                         uint32_t mrd, hipStream_t stream, bool clear = true)
 {
-    return launch_reduce(ctx, sl.d_red, sl.h_red, d_counts, d_bytes, n, mrd, stream);
+    return launch_reduce(ctx, sl.d_red, sl.h_red, d_counts, d_bytes, n, mrd, stream, clear);
 }
 
 // the partial results of a finished reduction (the stream has been synchronised), added up
@@ -955,11 +987,17 @@ static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mr
     // counts are always produced on the device (they feed the stats reduction); only what the
     // caller asked for crosses PCIe.
     const uint32_t dev_flags = (flags & (MBK_KERNEL_MASK | MBK_PRECISION_F32)) | MBK_WANT_COUNTS | (wb ? MBK_WANT_BYTES : 0u);
+    // The statistics: a pass over counts (+ bytes) after the tile kernel -- unless the kernel that serves this window can
+    // add up pixel-iterations and never-escaped pixels itself (the finish-in-place light pass: all-exterior tiles, 3 in 4
+    // of a pyramid level).  Then no int32 count is written unless the caller asked for counts, and the pass reads the
+    // bytes only (all-0 / all-1 flags, run count): 16 MiB instead of 80 for a DataChunk.
+    MBK_HIP(ctx, hipMemsetAsync(sl.d_red, 0, sizeof(ReduceSlot) * mbk::kReduceSlots, sl.stream));
+    bool fused = false;
     MBK_HIP(ctx, hipEventRecord(sl.ev_k0, sl.stream));
-    rc = launch_tile(ctx, view, mrd, dev_flags, sl.d_counts, sl.d_bytes, sl.stream);
+    rc = launch_tile(ctx, view, mrd, dev_flags, sl.d_counts, sl.d_bytes, sl.stream, nullptr, sl.d_red, !wc, &fused);
     if (rc != MBK_OK) return rc;
     MBK_HIP(ctx, hipEventRecord(sl.ev_k1, sl.stream));
-    rc = launch_reduce(ctx, sl, sl.d_counts, wb ? sl.d_bytes : nullptr, px, mrd, sl.stream);
+    rc = launch_reduce(ctx, sl, fused ? nullptr : sl.d_counts, wb ? sl.d_bytes : nullptr, px, mrd, sl.stream, false);
     if (rc != MBK_OK) return rc;
     MBK_HIP(ctx, hipEventRecord(sl.ev_c0, sl.stream));
     const bool lazy = wb && (flags & MBK_LAZY_UNIFORM) != 0;

@@ -36,6 +36,8 @@ struct Axis {
     uint32_t step_is_zero;  // numpy: y = (k/div)*delta instead of k*step
 };
 
+struct ReduceSlot;   // (below: partial results of the statistics reduction)
+
 struct TileArgs {
     Axis re, im;
     uint32_t col0, row0, ncols, nrows;
@@ -59,6 +61,9 @@ struct TileArgs {
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
     double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value
+    ReduceSlot *stats;    // may be null; honoured by the finish-in-place light pass only (mbk_scan.h, kStats): the
+                          // kernel adds the tile's pixel-iterations and never-escaped count to these partial results
+                          // itself, so that a DataChunk needs no int32 counts in HBM at all
 };
 
 // np.linspace sample k (numpy/_core/function_base.py): two roundings, endpoint pinned.
@@ -197,9 +202,10 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
 // instructions a block costs outside its loop; on cfg2 that overhead is 15 M of 317 M instructions).
 // kCycle: the grouped loops retire exactly periodic orbits early (mbk_loops.inc, MBK_G_CYC).
 // (ucol, urow): the block's first column / row inside the window, wave-uniform; (lx, ly): this lane's pixel in the block.
+// Returns the lane's count (-1: the lane has no pixel -- outside the window).
 template <typename T, bool kFmaDouble, int kGroup, bool kCycle = false>
-__device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t ucol, uint32_t urow, uint32_t lx, uint32_t ly,
-                                            bool long_groups, bool interior = false)
+__device__ __forceinline__ int32_t block_pixel(const TileArgs &p, uint32_t ucol, uint32_t urow, uint32_t lx, uint32_t ly,
+                                               bool long_groups, bool interior = false)
 {
     const uint32_t lc = ucol + lx, lr = urow + ly;
     T cr, ci;
@@ -209,7 +215,7 @@ __device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t ucol, ui
         ci = (T)((double)(p.row0 + lr) * p.im.step + p.im.start);
         ring_test = ring_test && p.ring_possible != 0u;
     } else {
-        if (lc >= p.ncols || lr >= p.nrows) return;
+        if (lc >= p.ncols || lr >= p.nrows) return -1;
         cr = (T)axis_value(p.re, p.col0 + lc);
         ci = (T)axis_value(p.im, p.row0 + lr);
     }
@@ -247,6 +253,7 @@ __device__ __forceinline__ void block_pixel(const TileArgs &p, uint32_t ucol, ui
     if (p.counts) (p.counts + ubase)[loff] = count;
     if (p.bytes) (p.bytes + ubase)[loff] = quantise(count, p);
     if (p.smooth) (p.smooth + ubase)[loff] = smooth_value(count, (double)m);
+    return count;
 }
 
 // Kernels "asm" (kGroup = 0) and "group": one 8x8 block per wave, blockDim / 64 blocks per workgroup.

@@ -139,10 +139,18 @@ __device__ __forceinline__ void scan_list(const ScanArgs &s, uint32_t q, uint32_
 // pass 2 is launched: for windows in which the host probe found nothing that outlives the light pass (3 tiles in 4 of a
 // pyramid level), where the second launch cost 4.4 us to find empty lists behind a pass 1 of 20.  Correct whatever the
 // probe missed -- a block is computed by the same two routines either way -- only slower if it missed much.
-template <typename T, bool kCounts, bool kBytes, int kInline = 0>
+// kStats (finish-in-place form only): the kernel adds the tile's pixel-iterations and never-escaped count to
+// p.stats itself -- per lane in registers over the wave's blocks, one reduction and two atomics per wave -- so that a
+// tile whose caller wants bytes only (a DataChunk) writes no int32 counts and the reduction pass reads bytes only.
+template <typename T, bool kCounts, bool kBytes, int kInline = 0, bool kStats = false>
 __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
 {
+    static_assert(!kStats || kInline != 0, "fused statistics exist in the finish-in-place form only");
     const uint32_t lane = threadIdx.x;
+    uint32_t acc = 0;                       // counts of the blocks finished by the light path (<= 4 each)
+    unsigned long long heavy_iters = 0;     // pixel-iterations / never-escaped pixels of the blocks finished in place
+    uint32_t heavy_never = 0;
+    const uint32_t never_cap = p.mrd > 1 ? (uint32_t)p.mrd - 1u : 0u;
     if (kInline == 0 && blockIdx.x == 0) {  // clear the next launch's cursors
         unsigned int *w = reinterpret_cast<unsigned int *>(s.cur_next);
         for (uint32_t k = lane; k < (uint32_t)(sizeof(ScanCursors) / 4u); k += 64u) w[k] = 0u;
@@ -181,16 +189,20 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
             const T a0 = cr * cr;
             uint32_t row = p.row0 + by * 8u + ly, off = (ly * p.out_pitch + lx) * oscale, n = nrun;
             int32_t cnt;
-            const uint32_t unfinished = escape_light_run<kCounts, kBytes>(cr, a0, row, rowinc, p.im.step, p.im.start, cnt, cb, bb,
-                                                                          off, einc, s.qtab, n);
+            const uint32_t unfinished = escape_light_run<kCounts, kBytes, kStats>(cr, a0, row, rowinc, p.im.step, p.im.start, cnt, cb, bb,
+                                                                                  off, einc, s.qtab, n, &acc);
             by += (nrun - n) * s.stride_by;
             sweeps_here += nrun - n;
             if (unfinished != 0u) {
                 // the block at `by`: some lane is still inside after 4 steps (dense: all of them)
                 const bool dense = __ballot(cnt == 5) == ~0ull;
                 if (kInline != 0) {
-                    block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, s.long_groups != 0u && dense,
-                                                           bx < p.fast_bx_end && by < p.fast_by_end);
+                    const int32_t c = block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, s.long_groups != 0u && dense,
+                                                                             bx < p.fast_bx_end && by < p.fast_by_end);
+                    if (kStats && c >= 0) {
+                        heavy_iters += c > 0 ? (uint32_t)c : never_cap;
+                        heavy_never += c == 0 ? 1u : 0u;
+                    }
                 } else {
                     scan_list<kInline == 0>(s, q, by * p.blocks_x + bx, dense, staged_d, nd, staged_s, ns, lane);
                 }
@@ -200,7 +212,11 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
         } else {
             // not attempted: a ragged edge or the axis' pinned end point
             if (kInline != 0) {
-                block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, false, bx < p.fast_bx_end && by < p.fast_by_end);
+                const int32_t c = block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, false, bx < p.fast_bx_end && by < p.fast_by_end);
+                if (kStats && c >= 0) {
+                    heavy_iters += c > 0 ? (uint32_t)c : never_cap;
+                    heavy_never += c == 0 ? 1u : 0u;
+                }
             } else {
                 scan_list<kInline == 0>(s, q, by * p.blocks_x + bx, false, staged_d, nd, staged_s, ns, lane);
             }
@@ -217,6 +233,15 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
     if (kInline == 0) {
         if (nd != 0u) scan_flush(s, q, staged_d, nd, true, lane);
         if (ns != 0u) scan_flush(s, q, staged_s, ns, false, lane);
+    }
+    if (kStats) {
+        // (acc cannot wrap: <= 4 per block, and a wave has fewer than 2^26 blocks)
+        const unsigned long long iters = wave_sum_u64(heavy_iters + acc), never = wave_sum_u64((unsigned long long)heavy_never);
+        ReduceOut *out = &p.stats[blockIdx.x % kReduceSlots].r;
+        if (lane == 0) {
+            if (iters) atomicAdd(&out->pixel_iterations, iters);
+            if (never) atomicAdd(&out->never_pixels, never);
+        }
     }
 }
 
