@@ -341,9 +341,11 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, 0, stream, a);
     else if (kernel == MBK_KERNEL_ASM)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, 0, stream, a);
-    else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 16 && cyc)
+    else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 32 && !cyc)   // (with the cycle test 32 means 16: mbk_loops.inc)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 32>), grid, block, 0, stream, a);
+    else if (ctx->opt[MBK_OPT_GROUP_STEPS] >= 16 && cyc)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16, true>), grid, block, 0, stream, a);
-    else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 16)
+    else if (ctx->opt[MBK_OPT_GROUP_STEPS] >= 16)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16>), grid, block, 0, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 8 && cyc)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8, true>), grid, block, 0, stream, a);
@@ -532,7 +534,7 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     if (a.bytes && a.mrd > 0)
         for (uint32_t k = 1; k <= 4u; ++k)
             s.qtab |= (uint32_t)(((uint64_t)k * 256u + (uint32_t)a.mrd - 1u) / (uint32_t)a.mrd & 0xffu) << (8u * (k - 1u));
-    s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] == 16u ? 1u : 0u;
+    s.long_groups = ctx->opt[MBK_OPT_GROUP_STEPS] >= 16u ? 1u : 0u;   // (the scan path has no 32-step form: 32 means 16)
     set_window_facts(a, f32);
 #define MBK_LAUNCH_LIGHT(INL)                                                                                              \
     do {                                                                                                                   \
@@ -1222,7 +1224,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
     switch (option) {
         case MBK_OPT_ORDER: ok = value <= 2u; break;
         case MBK_OPT_WAVES_PER_WG: ok = value == 1u || value == 2u || value == 4u; break;
-        case MBK_OPT_GROUP_STEPS: ok = value == 4u || value == 8u || value == 16u; break;
+        case MBK_OPT_GROUP_STEPS: ok = value == 4u || value == 8u || value == 16u || value == 32u; break;
         case MBK_OPT_EXACT_STEPS: ok = value <= 4096u; break;
         case MBK_OPT_PROBE_STEPS: ok = value >= 2u && value <= 65536u; break;
         case MBK_OPT_SCAN_WAVES: ok = value >= 1u && value <= 8u; break;

@@ -233,6 +233,10 @@ __device__ __forceinline__ int32_t block_pixel(const TileArgs &p, uint32_t ucol,
         }
         if (risky) {
             count = escape_count_asm<true>(cr, ci, p.mrd, &m);
+        } else if (kGroup == 32) {
+            // 32-step groups (6.0625 slots per step; strict loops only) for the blocks classified as interior, 8 elsewhere
+            count = long_groups ? escape_count_group<32, false>(cr, ci, p.mrd, &m, p.exact_steps_long)
+                                : escape_count_group<8, false>(cr, ci, p.mrd, &m, p.exact_steps);
         } else if (kGroup == 16) {
             // 16-step groups (6.125 issue slots per step) only where the test hardly ever trips (interior of
             // the set: the blocks a probe or the light pass classified as such); 8 elsewhere
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     }
     const uint32_t wcol = bx * (blockDim.x >> 6) + wave;  // one 8x8 block per wave
     // the blocks the heavy-first probe put at the front of the dispatch order take the 16-step groups
-    const bool long_groups = kGroup == 16 && (!p.order || blockIdx.x < n_heavy);   // wave-uniform
+    const bool long_groups = kGroup >= 16 && (!p.order || blockIdx.x < n_heavy);   // wave-uniform
     const bool interior = wcol < p.fast_bx_end && by < p.fast_by_end;                        // wave-uniform
     block_pixel<T, kFmaDouble, kGroup, kCycle>(p, wcol * 8u, by * 8u, lane & 7u, lane >> 3, long_groups, interior);
 }

@@ -229,9 +229,10 @@ enum mbk_option {
     MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] heavy-first list
                               (probe never escaped first; optionally a middle class, MBK_OPT_PROBE_MID) */
     MBK_OPT_WAVES_PER_WG,  /* asm/group: 8x8 blocks per workgroup: [1], 2, 4 */
-    MBK_OPT_GROUP_STEPS,   /* group: steps per grouped bailout test: 4, 8, [16] (16 applies to the blocks classified as
+    MBK_OPT_GROUP_STEPS,   /* group: steps per grouped bailout test: 4, 8, [16], 32 (16 / 32 apply to the blocks classified as
                               interior -- probe-heavy / dense --, the rest keep 8).  Scan pass 2 and the fp32 loops have no
-                              4-step form: there 4 means 8 (and the cycle test needs >= 8, so 4 in "group" runs without it) */
+                              4-step form: there 4 means 8 (and the cycle test needs >= 8, so 4 in "group" runs without it).
+                              32 exists for the fp64 "group" kernel without the cycle test only; everywhere else it means 16 */
     MBK_OPT_EXACT_STEPS,   /* group / scan pass 2: steps tested one by one before the grouped test takes over: 0..4096 [8] */
     MBK_OPT_PROBE_STEPS,   /* asm/group: depth of the heavy-first probe: 2..65536 [32] */
     MBK_OPT_SCAN_WAVES,    /* scan: resident waves per SIMD of pass 1: 1..[8] */

@@ -404,6 +404,8 @@ OPTION_MATRIX = [
     ("default", {"heavy_share": 0}), ("default", {"heavy_share": 65536}),
     ("group", {"prepass_overlap": 0}), ("default", {"prepass_overlap": 0, "probe_mid": 6}),
     ("group", {"exact_long": 0}), ("scan", {"exact_long": 0, "cycle_detect": 0}), ("default", {"exact_long": 3, "exact_steps": 5}),
+    ("group", {"group_steps": 32, "cycle_detect": 0}), ("group", {"group_steps": 32}), ("default", {"group_steps": 32, "cycle_detect": 0, "exact_long": 8}),
+    ("scan", {"group_steps": 32, "cycle_detect": 0}),
     ("scan", {"scan_inline": 0}), ("default", {"scan_inline": 0, "cycle_detect": 0}), ("scan", {"scan_inline": 1, "scan_waves": 2, "cycle_detect": 0}),
 ]
 
