@@ -685,7 +685,7 @@ def main():
         achieved_tflops = FLOPS_PER_PIXEL_ITER * per_gpu_iters / avg_kernel_s / 1e12
         slots = VALU_SLOTS_PER_PIXEL_ITER.get(args.kernel, 8.0)
         if args.kernel in ("default", "scan", "group") and options.get("group_steps", 16) != 16:
-            slots = 6.25 if options["group_steps"] == 8 else 6.5
+            slots = {8: 6.25, 32: 6.0625 if args.kernel != "scan" else 6.125}.get(options["group_steps"], 6.5)
         if options.get("cycle_detect", 0) and args.kernel in ("default", "scan", "group") and options.get("group_steps", 16) != 4:
             slots += 0.125     # two bitwise state compares per 16 steps
         launches_per_step = ntiles if queue_mode else 1

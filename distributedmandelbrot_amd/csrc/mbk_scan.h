@@ -10,17 +10,28 @@
 //
 //   pass 1  tile_light_kernel   a grid that fills the chip once; wave w takes blocks w, w+W, w+2W, ...  W is
 //           a whole number of block rows, so a wave stays in one block column (real coordinate and its
-//           square computed once) for `col_period` sweeps, then jumps to a far column (otherwise the waves
-//           whose column crosses the set would carry all the unfinished blocks).  Per interior block ONE asm
-//           sequence (mbk_loops.inc: escape_light_block): imaginary coordinate, |c| = 2 ring check, four
-//           branch-free steps of the reference loop (WorkerCUDA.py:39-68), and -- if every lane escaped --
-//           the stores, addressed as uniform base + constant lane offset.  ~30 VALU and ~20 scalar
-//           instructions per block.  A block that is not finished (a lane still inside after 4 steps, a
-//           pixel near the ring, a ragged edge, the axis' pinned end point) is put on a TODO list, nothing
-//           else: its id goes into a lane of a staging register (v_writelane, no memory traffic), and the
-//           wave appends its staged ids to one of 64 lists with one atomicAdd per 64 ids ("dense" blocks --
-//           all 64 lanes still inside: interior of the set or of a slow region -- to the front of the
-//           list's slab, the others to its back).
+//           square computed once per run) for `col_period` sweeps, then jumps to a far column (otherwise the waves
+//           whose column crosses the set would carry all the unfinished blocks).  A wave's consecutive interior blocks
+//           are ONE asm loop (mbk_loops.inc: escape_light_run, round 3): imaginary coordinate, up to four steps of
+//           the reference loop (WorkerCUDA.py:39-68) with the reference's own test -- a lane whose |z|^2 >= 4 takes
+//           its step index and leaves EXEC, so the path is exact by construction (no ">= 4 stays >= 4" argument, no
+//           |c| = 2 ring check) -- and, when no lane is left, the stores, addressed as uniform base + 32-bit lane
+//           offset; ~22 VALU and ~12 scalar instructions for a block that is gone after two steps.  (Round 2 ran a
+//           per-block asm body inside the compiler's loop: ~30 VALU + ~33 scalar instructions, and the CU's scalar
+//           unit issues one instruction per cycle for all four SIMDs -- the pass was scalar-bound: 23 us for the
+//           all-exterior tile where the bare body needed 15.)  The loop stops at a block that is not finished (a
+//           lane still inside after 4 steps); that block, and every block that cannot take the light path (a ragged
+//           edge, the axis' pinned end point), is either
+//           * put on a TODO list (kInline = 0): its id goes into a lane of a staging register (v_writelane, no
+//             memory traffic), and the wave appends its staged ids to one of 64 lists with one atomicAdd per 64 ids
+//             ("dense" blocks -- all 64 lanes still inside: interior of the set or of a slow region -- to the front
+//             of the list's slab, the others to its back); or
+//           * finished on the spot by the same wave with the code of kernel "group" (kInline = 1 / 2, block_pixel),
+//             and pass 2 is not launched at all: the form for windows in which the host's probe finds nothing that
+//             outlives the light pass -- all-exterior tiles, 3 in 4 of a pyramid level -- where the second launch
+//             cost 4.4 us to find empty lists.  In this form the kernel can also add up the tile's statistics
+//             (kStats: pixel-iterations and never-escaped pixels, per lane in registers, two atomics per wave), so a
+//             DataChunk of such a tile writes its 16 MiB of bytes and no int32 counts.
 //   pass 2  tile_todo_kernel    one single-wave workgroup per listed block, dealt by the hardware dispatcher
 //           (workgroup j: element j div 64 of list j mod 64, dense elements first: longest jobs first),
 //           which computes the block from scratch exactly like kernel "group" (block_pixel: per-step

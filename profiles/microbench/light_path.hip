@@ -17,6 +17,32 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
+// The arithmetic of the light path alone (modes compute / strip_c): four branch-free steps of the reference loop, an
+// escaped lane keeps iterating, cnt = 1 + number of steps it stayed inside (round 2's light path; the product now
+// narrows EXEC instead -- mbk_loops.inc: escape_light_run -- at the same instruction count per step).
+#define LP_STEP                                  \
+    "v_add_f64 %[t], %[a], -%[b]\n"              \
+    "v_mul_f64 %[p], %[zr], %[zi]\n"             \
+    "v_add_f64 %[zr], %[t], %[cr]\n"             \
+    "v_fma_f64 %[zi], %[p], 2.0, %[ci]\n"        \
+    "v_mul_f64 %[a], %[zr], %[zr]\n"             \
+    "v_mul_f64 %[b], %[zi], %[zi]\n"             \
+    "v_add_f64 %[m], %[a], %[b]\n"               \
+    "v_cmp_gt_f64 vcc, 4.0, %[m]\n"              \
+    "v_addc_co_u32_e64 %[cnt], %[tmp], %[cnt], 0, vcc\n" \
+    "s_cbranch_vccz .Lprodone_%=\n"
+__device__ __forceinline__ void prologue4(double cr, double ci, double &zr, double &zi, double &a, double &b, int32_t &cnt)
+{
+    double t, p, m;
+    unsigned long long tmp;
+    cnt = 1;
+    asm volatile(LP_STEP LP_STEP LP_STEP LP_STEP ".Lprodone_%=:\n"
+                 : [zr] "+&v"(zr), [zi] "+&v"(zi), [a] "+&v"(a), [b] "+&v"(b), [cnt] "+&v"(cnt), [m] "=&v"(m),
+                   [t] "=&v"(t), [p] "=&v"(p), [tmp] "=&s"(tmp)
+                 : [cr] "v"(cr), [ci] "v"(ci)
+                 : "vcc");
+}
+
 enum Mode { COMPUTE, STORE8, STORE8X, STORE64, BOTH, BOTHX, STRIP, STRIPC };
 
 template <int MODE>
@@ -57,7 +83,7 @@ __global__ __launch_bounds__(64) void light_kernel(int32_t *out, double start, d
                 } else {
                     ci = (double)row * step + start;
                     zr = crs; zi = ci; a = a0s; b = ci * ci;
-                    mbk::escape_steps_prologue4(crs, ci, zr, zi, a, b, cnt);
+                    prologue4(crs, ci, zr, zi, a, b, cnt);
                 }
                 acc += cnt;
             }
@@ -89,7 +115,7 @@ __global__ __launch_bounds__(64) void light_kernel(int32_t *out, double start, d
             {   // arithmetic only: the plain prologue on the same coordinates
                 ci = (double)(by * 8u + ly) * step + start;
                 zr = cr; zi = ci; a = a0; b = ci * ci;
-                mbk::escape_steps_prologue4(cr, ci, zr, zi, a, b, cnt);
+                prologue4(cr, ci, zr, zi, a, b, cnt);
             }
             acc += cnt;
         }
