@@ -30,6 +30,12 @@ if ! skip n2; then echo "== N > 1 path: the plain command, two ranks sharing thi
   b bands_n2_oversub --gpus 2 --oversubscribe --shard bands --workload cfg3 --steps 4
   b bands_n1_cfg3 --shard bands --workload cfg3 --steps 6 --no-cpu-baseline
 fi
+echo "== round 3, second half: light pass (finish-in-place against the two-pass form), 32-step groups, microbenchmarks"
+b exterior_twopass --workload exterior --no-cpu-baseline --no-extras --opt scan_inline=0
+b cfg2_g32 --no-cpu-baseline --no-extras --opt group_steps=32
+b cfg3_g32 --workload cfg3 --no-cpu-baseline --no-extras --opt group_steps=32
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/light_path profiles/microbench/light_path.hip 2> "$OUT/build_mb.log" && timeout 300 /tmp/light_path > "$OUT/light_path_microbench.txt" 2>&1; cat "$OUT/light_path_microbench.txt"
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/mfma_f64 profiles/microbench/mfma_f64_coissue.hip 2>> "$OUT/build_mb.log" && timeout 300 /tmp/mfma_f64 > "$OUT/mfma_f64_coissue.txt" 2>&1; grep -E "V0|V1  zi|V5|V6" "$OUT/mfma_f64_coissue.txt" | head -4
 echo "== rocprofv3 kernel traces"
 trace cfg2_default --no-extras
 trace cfg2_cycle --opt cycle_detect=1 --no-extras
@@ -46,6 +52,10 @@ if ! skip pmc; then echo "== rocprofv3 pmc (separate passes, no tracing)"
   pmcrun cfg2_a "$C1" --steps 20 --warmup 5; pmcrun cfg2_b "$C2" --steps 20 --warmup 5
   pmcrun cfg2_w "WRITE_SIZE" --steps 20 --warmup 5; pmcrun cfg2_f "FETCH_SIZE" --steps 20 --warmup 5
   python scripts/pmc_summary.py "$OUT/cfg2_default_pmc_by_kernel.json" "$OUT/pmc_cfg2_a" "$OUT/pmc_cfg2_b" "$OUT/pmc_cfg2_w" "$OUT/pmc_cfg2_f" --match tile_
+  pmcrun ext_a "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload exterior --steps 20 --warmup 5
+  pmcrun ext_w "WRITE_SIZE" --workload exterior --steps 20 --warmup 5; pmcrun ext_f "FETCH_SIZE" --workload exterior --steps 20 --warmup 5
+  python scripts/pmc_summary.py "$OUT/exterior_default_pmc_by_kernel.json" "$OUT/pmc_ext_a" "$OUT/pmc_ext_w" "$OUT/pmc_ext_f" --match tile_
+  rm -rf "$OUT"/pmc_ext_?
   for K in group refill; do
     pmcrun cfg3_${K}_a "$C1" --workload cfg3 --kernel $K --steps 4 --warmup 1 --opt cycle_detect=0
     pmcrun cfg3_${K}_b "$C2" --workload cfg3 --kernel $K --steps 4 --warmup 1 --opt cycle_detect=0

@@ -13,7 +13,7 @@ rs = np.random.RandomState(seed)
 o = COracle()
 combos = [("scan", "f64"), ("default", "f64"), ("group", "f64"), ("asm", "f64"), ("refill", "f64"), ("simple", "f64"),
           ("scan", "f32"), ("group", "f32"), ("asm", "f32")]
-OPTION_CHOICES = {"scan_waves": [1, 2, 8], "scan_xcd_map": [0, 1], "scan_col_period": [0, 1, 4], "group_steps": [4, 8, 16],
+OPTION_CHOICES = {"scan_waves": [1, 2, 8], "scan_xcd_map": [0, 1], "scan_col_period": [0, 1, 4], "group_steps": [4, 8, 16, 32], "scan_inline": [0, 1],
                   "exact_steps": [0, 3, 8, 20], "order": [0, 1, 2], "heavy_share": [0, 655, 65536], "waves_per_wg": [1, 2, 4],
                   "cycle_detect": [0, 1], "probe_mid": [2, 6, 65537], "prepass_overlap": [0, 1], "probe_steps": [2, 32, 200], "exact_long": [0, 4, 8]}
 t0 = time.time(); n = 0; px = 0
@@ -54,10 +54,16 @@ while time.time() - t0 < budget:
         window = (c0, r0, int(rs.randint(1, w - c0 + 1)), int(rs.randint(1, h - r0 + 1)))
     kernel, prec = combos[rs.randint(0, len(combos))]
     oc, ob, total = o.view(view.start_r, view.start_i, view.range_r, view.range_i, w, h, mrd, window=window, precision=prec)
-    outs = rs.randint(0, 3) if kernel != "refill" else 0       # 0: host API (counts + bytes); 1: bytes only; 2: counts only
-    if outs == 0:
-        c, b, st = dev.compute_view(view, mrd, window=window, kernel=kernel, precision=prec)
-        ok = np.array_equal(c, oc) and np.array_equal(b, ob) and st.pixel_iterations == total
+    outs = rs.randint(0, 5) if kernel != "refill" else 0       # 0: host API (counts + bytes); 1: bytes only; 2: counts only;
+                                                               # 3 / 4: host API with bytes only / counts only (statistics may be fused)
+    if outs == 0 or outs >= 3:
+        c, b, st = dev.compute_view(view, mrd, window=window, kernel=kernel, precision=prec, want_counts=outs != 3, want_bytes=outs != 4)
+        ok = (c is None or np.array_equal(c, oc)) and (b is None or np.array_equal(b, ob)) and st.pixel_iterations == total \
+            and st.never_pixels == int((oc == 0).sum())
+        if b is not None:
+            ok = ok and st.rle_runs == 1 + int((ob.ravel()[1:] != ob.ravel()[:-1]).sum()) and st.all_bytes_zero == bool((ob == 0).all())
+        if c is None:
+            c = b
     else:                                                        # device-pointer launch with a single output
         npx = oc.size
         t = torch.full((npx,), 77, dtype=torch.uint8 if outs == 1 else torch.int32, device="cuda:0")
@@ -70,7 +76,7 @@ while time.time() - t0 < budget:
         ok = np.array_equal(got, ob if outs == 1 else oc)
     if not ok:
         print("MISMATCH", kernel, prec, opts, "outs", outs, view, mrd, window, flush=True)
-        ref = ob if outs == 1 else oc
+        ref = ob if outs in (1, 3) else oc
         idx = np.argwhere(c != ref)[:5]
         print([(int(r), int(cc), int(c[r, cc]), int(ref[r, cc])) for r, cc in idx])
         sys.exit(1)
