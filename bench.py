@@ -137,12 +137,17 @@ def parse_args(argv=None):
                          "that the ranks pull from a shared-memory cursor (strong scaling; the per-GPU work queue of the "
                          "north star). bands: ONE view per step, cut into >= 16 row bands per GPU pulled from the cursor "
                          "(strong scaling; how BASELINE cfg3 shards an image over 8 GPUs)")
+    ap.add_argument("--queue-order-image", action="store_true",
+                    help="--shard queue: hand the tiles of a step out in image order instead of longest first")
     ap.add_argument("--grid", type=int, default=8, help="--shard queue: the job is grid x grid tiles (default 8 -> 64 tiles per step)")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for --shard bands (default: height / (16 N), >= 128)")
     ap.add_argument("--streams", type=int, default=None,
                     help="tiles (or bands) in flight per GPU (default 1 for own = the contract's serial steps, 2 for queue / bands)")
     ap.add_argument("--control", default="gloo", choices=["gloo", "nccl"],
                     help="backend of the barrier / timing reductions for N > 1 (no data-path collective exists)")
+    ap.add_argument("--no-solo", action="store_true",
+                    help="N > 1, queue / bands: skip the single-GPU pass of the same job that rank 0 runs alone after the "
+                         "timed region (`single_gpu_same_job`; it takes N times as long as the timed region)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="functional test only: rank r uses GPU r mod (visible GPUs), so that the N > 1 path can be "
                          "exercised on a box with fewer GPUs than ranks (labelled in config; never a scaling number)")
@@ -354,8 +359,9 @@ def main():
         args.shard = "queue" if world > 1 else "own"
     own_mode, queue_mode, bands_mode = args.shard == "own", args.shard == "queue", args.shard == "bands"
     d_steps, d_warm = DEFAULT_STEPS.get(args.workload, (20, 3))
-    if queue_mode:   # a step is grid^2 tiles, not one
-        d_steps, d_warm = max(2, d_steps * 4 // (args.grid * args.grid)), 1
+    if queue_mode:   # a step is grid^2 tiles, not one; the timed region keeps its length per GPU as N grows (the job of
+        # a step is fixed -- strong scaling -- but more steps are timed: at N = 8 the 25 steps of N = 1 would last 0.1 s)
+        d_steps, d_warm = max(2, d_steps * 4 // (args.grid * args.grid)) * world, 1
     if args.steps is None:
         args.steps = d_steps
     if args.warmup is None:
@@ -438,9 +444,8 @@ def main():
         def launch_own(i):
             time.sleep(0.001)
 
-        def launch_unit(i, u):
-            k = u.index if bands_mode else u
-            time.sleep(0.0002 * (1 + k % 3))
+        def launch_unit(i, u):   # stub cost: per band row / per tile class (so that a chunk of bands costs its rows)
+            time.sleep(2e-6 * u.nrows if bands_mode else 0.0002 * (1 + u % 3))
 
         def unit_stats(u):          # (pixel-iterations, never-escaped pixels) of a queue tile
             return 10 ** 7 * (1 + u % 3), u % 3
@@ -517,8 +522,9 @@ def main():
     my_tickets = []
     launches = [0]
 
-    def run_steps(nsteps, events=None):
-        """own: nsteps launches round-robin over the streams.  queue / bands: pull tickets until nsteps steps are done."""
+    def run_steps(nsteps, events=None, pullers=world):
+        """own: nsteps launches round-robin over the streams.  queue / bands: pull tickets until nsteps steps are done
+        (`pullers` = the ranks pulling from the cursor: it sizes the guided chunks of the bands mode)."""
         if own_mode:
             for _ in range(nsteps):
                 i = turn[0] % nstreams
@@ -540,7 +546,7 @@ def main():
                 # guided self-scheduling: a launch's efficiency grows with its size (a band of a deep zoom cannot be
                 # shorter than its slowest block: 512-row bands of cfg3 run at 0.81 of the whole image's rate, 128-row
                 # bands at 0.66), so a rank takes remaining / (2 N) consecutive bands of one image as ONE window
-                t, k = cursor.next_guided(limit, 2 * world, period=len(units))
+                t, k = cursor.next_guided(limit, 2 * pullers, period=len(units))
                 if k == 0:
                     break
                 first, last = units[t % len(units)], units[t % len(units) + k - 1]
@@ -575,6 +581,11 @@ def main():
     per_tile = None
     if queue_mode:
         per_tile = census()
+        # hand the tiles of a step out longest first (by the census' pixel-iterations; every rank holds the same table):
+        # the last tickets of the run are then the cheapest tiles, so the ranks finish together -- the order a
+        # Distributer hands tiles out in is the server's choice (Distributer.cs:335-353 walks its own list)
+        if not args.queue_order_image:
+            units = sorted(units, key=lambda u: (-per_tile[u][0], u))
         barrier()
         if rank == 0:
             cursor.reset(0)
@@ -614,6 +625,29 @@ def main():
         st = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
         iters_per_step, never = st.pixel_iterations, st.never_pixels
         kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
+
+    # N > 1, strong-scaling modes: the SAME job on ONE GPU, timed in this very run.  N = 1 defaults
+    # to one tile per step (`--shard own`: the contract's headline), N > 1 to the tile queue, whose single-GPU rate is
+    # ~1.07x the headline's (finer pitch, more coherent blocks) -- so value(N) / value(1) across the two commands would
+    # overstate the speed-up.  Here rank 0 pulls every ticket of the same steps from the same cursor, alone, while the
+    # other ranks sit in a barrier (untimed for them); `single_gpu_same_job` in the line then gives the denominator
+    # that belongs to `value`.  Errors are caught: this leg must not cost the headline (the barriers are unconditional).
+    solo = None
+    if world > 1 and not own_mode and not args.no_solo:
+        barrier()
+        if rank == 0:
+            cursor.reset(0)
+            try:
+                run_steps(1, pullers=1)            # untimed: the GPU has idled through the barrier
+                sync()
+                cursor.reset(0)
+                ts = time.perf_counter()
+                run_steps(args.steps, pullers=1)
+                sync()
+                solo = time.perf_counter() - ts
+            except Exception as e:   # noqa: BLE001 -- reported in the line, not swallowed
+                solo = repr(e)
+        barrier()
 
     # second leg (own mode, fp64/fp32 count kernels): the same K steps with the library's default cycle test.
     # A failure here must not cost the headline: errors are caught (the barriers stay unconditional, so the ranks
@@ -728,6 +762,7 @@ def main():
             tile_iters = [per_tile[k][0] for k in range(ntiles)]
             cfg.update({"tiles_per_step": ntiles, "grid": args.grid, "tiles_exactly_once": once,
                         "tiles_per_rank": per_rank_units,
+                        "tile_order": "image order" if args.queue_order_image else "longest first within a step (census)",
                         "tile_pixel_iterations_min_max": [min(tile_iters), max(tile_iters)]})
         rec = {
             "metric": metric,
@@ -766,6 +801,18 @@ def main():
                 "hbm_GBps": out_bytes / avg_kernel_s / 1e9,
             },
         }
+        if isinstance(solo, float):
+            solo_value = iters_all * args.steps / solo / 1e9
+            rec["single_gpu_same_job"] = {
+                "what": "the same job (same tiles / bands, same steps, same cursor, same streams in flight) pulled by rank 0 "
+                        "alone on its one GPU right after the timed region, the other ranks waiting in a barrier: the N = 1 "
+                        "point that belongs to `value` (the plain `--gpus 1` command measures one tile per step instead)",
+                "value": solo_value, "unit": "G pixel-iterations/s", "ms_per_step": solo / args.steps * 1e3,
+                "steps": args.steps, "gpu": me.get("pci_bus_id")}
+            rec["speedup_same_job"] = rec["value"] / solo_value
+            rec["efficiency_same_job"] = rec["value"] / (world * solo_value)
+        elif solo is not None:
+            rec["single_gpu_same_job"] = {"error": solo}
         if cyc_leg is not None:
             rec["cycle_detection"] = {
                 "what": "same workload and steps with MBK_OPT_CYCLE_DETECT=1 (library default): pixels whose (zr, zi) bit "

@@ -157,6 +157,11 @@ def test_bench_bands_dynamic_cursor_gloo_world2():
     assert cfg["bands_per_image"] == 32 and cfg["band_rows"] == 256          # >= 16 bands per GPU (of >= 128 rows)
     assert cfg["bands_exactly_once"] is True
     assert sum(cfg["bands_per_rank"]) == 3 * 32 and min(cfg["bands_per_rank"]) > 0
+    # the same images on one rank alone, timed in the same run: the denominator that belongs to `value`
+    solo = rec["single_gpu_same_job"]
+    assert solo["steps"] == 3 and solo["value"] > 0
+    assert abs(rec["speedup_same_job"] - rec["value"] / solo["value"]) < 1e-9
+    assert abs(rec["efficiency_same_job"] - rec["speedup_same_job"] / 2) < 1e-9
     assert not os.path.exists(os.path.join("/dev/shm", "mbk_cursor_%d_none" % port))
 
 
@@ -185,6 +190,24 @@ def test_bench_self_launch_queue_default_world2():
     # the stub's per-tile work is 1e7 * (1 + t % 3): the census must have measured every tile once
     per_step = sum(10 ** 7 * (1 + t % 3) for t in range(64))
     assert abs(rec["value"] - per_step * 3 / (rec["ms_per_step"] * 3 / 1e3) / 1e9) / rec["value"] < 1e-6
+    # rank 0 then ran the same 3 steps alone (the other rank in a barrier): single-GPU rate of the SAME job, in the line
+    solo = rec["single_gpu_same_job"]
+    assert solo["steps"] == 3 and 0 < solo["value"] < rec["value"] * 1.05
+    assert abs(rec["speedup_same_job"] - rec["value"] / solo["value"]) < 1e-9
+    assert abs(rec["efficiency_same_job"] - rec["speedup_same_job"] / 2) < 1e-9 and rec["efficiency_same_job"] > 0.6
+    assert cfg["tile_order"].startswith("longest first")
+
+
+def test_bench_queue_default_steps_grow_with_the_ranks():
+    """The job of a step is fixed (64 tiles) but the default number of timed steps grows with N, so that the timed
+    region per GPU keeps its length; --no-solo drops the single-GPU pass."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env["MBK_BENCH_FAKE"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "2", "--no-solo"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["steps"] == 2 * 400 and rec["config"]["tiles_exactly_once"] is True and "single_gpu_same_job" not in rec
 
 
 def test_bench_self_launch_reports_a_dead_rank():
@@ -285,3 +308,46 @@ def test_bench_json_contract_single_rank_fake():
     assert rec["scaling"] == "weak" and rec["config"]["shard"] == "own" and rec["config"]["launcher"] == "single process"
     assert len(rec["config"]["ranks_seen"]) == 1 and rec["config"]["distinct_gpus"] == 1
     assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-12
+
+
+def _run_bench_two_ranks_one_gpu(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "MBK_BENCH_FAKE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "2",
+                          "--warmup", "1"] + extra, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_real_bench_two_ranks_share_the_gpu_queue():
+    """The REAL N > 1 path -- two processes, each with its own MandelbrotDevice, torch streams, the shared cursor and
+    gloo -- on this box's one GPU (`--oversubscribe`: a functional test, never a scaling number).  Every ticket of
+    the timed region exactly once, both ranks fed, two pids, no stub; and the same-job single-GPU pass is in the line."""
+    rec = _run_bench_two_ranks_one_gpu([])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and cfg["shard"] == "queue" and cfg["fake_backend"] is False
+    assert cfg["oversubscribed"] is True and cfg["tiles_exactly_once"] is True
+    assert sum(cfg["tiles_per_rank"]) == 2 * 64 and min(cfg["tiles_per_rank"]) > 0
+    seen = cfg["ranks_seen"]
+    assert len({r["pid"] for r in seen}) == 2 and all(r["pci_bus_id"] for r in seen) and cfg["distinct_gpus"] == 1
+    solo = rec["single_gpu_same_job"]
+    assert "error" not in solo and solo["value"] > 1000.0          # G pixel-iterations/s of one MI355X on this job
+    assert 0.5 < rec["speedup_same_job"] < 1.3                     # two ranks time-slicing ONE GPU cannot beat it by much
+    # the census measured every tile from the kernels' own output: the job holds far-exterior and all-interior tiles
+    lo, hi = cfg["tile_pixel_iterations_min_max"]
+    assert hi > 100 * lo > 0
+
+
+@pytest.mark.gpu
+def test_real_bench_two_ranks_share_the_gpu_cfg3_bands():
+    """BASELINE cfg3's strong-scaling form (one 8192^2 deep-zoom image per step, row bands from the shared cursor) with
+    two real ranks on the one GPU."""
+    rec = _run_bench_two_ranks_one_gpu(["--workload", "cfg3", "--shard", "bands"])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and cfg["shard"] == "bands" and cfg["fake_backend"] is False
+    assert cfg["bands_exactly_once"] is True and sum(cfg["bands_per_rank"]) == 2 * cfg["bands_per_image"]
+    assert min(cfg["bands_per_rank"]) > 0 and len({r["pid"] for r in cfg["ranks_seen"]}) == 2
+    assert cfg["pixel_iterations_per_step_per_gpu"] * 2 > 6.0e10   # the whole image's work was measured (~65 G)
+    assert "error" not in rec["single_gpu_same_job"] and rec["single_gpu_same_job"]["value"] > 1000.0
