@@ -362,6 +362,8 @@ def main():
     if queue_mode:   # a step is grid^2 tiles, not one; the timed region keeps its length per GPU as N grows (the job of
         # a step is fixed -- strong scaling -- but more steps are timed: at N = 8 the 25 steps of N = 1 would last 0.1 s)
         d_steps, d_warm = max(2, d_steps * 4 // (args.grid * args.grid)) * world, 1
+    if bands_mode:   # likewise: an image is a fixed job, the number of timed images grows with N
+        d_steps *= world
     if args.steps is None:
         args.steps = d_steps
     if args.warmup is None:

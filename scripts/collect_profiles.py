@@ -1,4 +1,4 @@
-"""Copy the judged summaries of a gpurun_out/<tag> directory (written by scripts/gpu_round.sh) into
+"""Copy the judged summaries of a gpurun_out/<tag> directory (written by scripts/gpu_run.sh) into
 profiles/<round>/ (tracked).   python scripts/collect_profiles.py <tag> <round>"""
 import glob, json, os, shutil, sys
 
@@ -15,7 +15,9 @@ for f in sorted(glob.glob(os.path.join(src, "power_*.json"))):
     shutil.copy(f, dst)
 for extra in ("rocminfo.txt", "nproc.txt", "valu_rates.log", "level16.log", "worker_e2e.log", "cfg2_default_pmc_by_kernel.json", "soak.log",
               "pytest_gpu.log", "cfg3_group_pmc.json", "cfg3_refill_pmc.json", "source_sha256.txt", "smoke.log",
-              "light_path_microbench.txt", "mfma_f64_coissue.txt", "exterior_default_pmc_by_kernel.json"):
+              "light_path_microbench.txt", "mfma_f64_coissue.txt", "exterior_default_pmc_by_kernel.json", "pytest_gpu.txt", "soak.txt",
+              "valu_issue.txt", "scale_prediction.json", "scale_emulate.txt", "cfg3_default_pmc_by_kernel.json",
+              "chunk_l1_default_pmc_by_kernel.json"):
     p = os.path.join(src, extra)
     if os.path.exists(p):
         out = extra.replace("valu_rates.log", "valu_rates_microbench.txt").replace("soak.log", "soak.txt").replace("pytest_gpu.log", "pytest_gpu.txt")

@@ -1,0 +1,88 @@
+#!/bin/bash
+# The one parameterised GPU pass (round 4; replaces the one-off gpu_r3?.sh scripts).  Usage, on the GPU box:
+#     scripts/gpu_run.sh TAG section [section ...]
+# Everything lands in gpurun_out/TAG/.  Sections (run in the order given):
+#   smoke        __graft_entry__.smoke()
+#   tests        the whole `pytest -m gpu` suite            tests:EXPR  only tests matching -k EXPR
+#   soak[:S]     randomized parity soak for S seconds (default 120)
+#   issue        profiles/microbench/valu_issue.hip (fp64 issue rate in shader cycles)
+#   headline     bench.py as the driver runs it
+#   n2           the N > 1 paths with two ranks on this box's one GPU (--oversubscribe; functional)
+#   emulate      scripts/scale_emulate.py -> scale_prediction.json
+#   benches      the other bench lines (kernels, workloads)
+#   ab:NAME=V    same-box A/B of a library option: cfg2 / chunk_l1 / cfg3 with and without --opt NAME=V, twice, interleaved
+#   traces       rocprofv3 --kernel-trace --stats of the named workloads
+#   pmc          rocprofv3 --pmc passes (cfg2 with the source hash, cfg3)
+#   power        power / clock traces
+#   e2e          level rate, worker end to end
+set -u
+TAG=${1:?tag}; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
+source scripts/gpu_lib.sh
+rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock|gfx" | head -12 > "$OUT/rocminfo.txt" 2>&1; nproc > "$OUT/nproc.txt"
+python -c "
+import sys; sys.path.insert(0, '.'); import bench; print(bench.kernel_source_hash())" > "$OUT/source_sha256.txt"; cat "$OUT/source_sha256.txt"
+for SEC in "$@"; do
+  ARG=""; case "$SEC" in *:*) ARG=${SEC#*:}; SEC=${SEC%%:*};; esac
+  echo "== $SEC $ARG"
+  case "$SEC" in
+  smoke) timeout 600 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -1 "$OUT/smoke.log";;
+  tests) if [ -n "$ARG" ]; then timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider -k "$ARG" > "$OUT/pytest_gpu_subset.txt" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest_gpu_subset.txt"; grep -E "^FAILED|^ERROR" "$OUT/pytest_gpu_subset.txt" | cut -c1-300 | head -10
+         else timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > "$OUT/pytest_gpu.txt" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest_gpu.txt"; grep -E "^FAILED|^ERROR" "$OUT/pytest_gpu.txt" | cut -c1-300 | head -10; fi;;
+  soak) timeout 900 python scripts/gpu_soak.py ${ARG:-120} 17 > "$OUT/soak.txt" 2>&1; tail -2 "$OUT/soak.txt";;
+  issue) hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue profiles/microbench/valu_issue.hip 2> "$OUT/build_issue.log" && timeout 300 /tmp/valu_issue > "$OUT/valu_issue.txt" 2>&1; cut -c1-200 "$OUT/valu_issue.txt";;
+  headline) b cfg2_default;;
+  n2) b queue_n1 --shard queue --no-cpu-baseline
+      b queue_n2_oversub --gpus 2 --oversubscribe
+      b bands_n2_oversub --gpus 2 --oversubscribe --shard bands --workload cfg3 --steps 6
+      b cfg3_queue_n2_oversub --gpus 2 --oversubscribe --workload cfg3 --grid 2 --steps 6
+      for f in queue_n2_oversub bands_n2_oversub cfg3_queue_n2_oversub; do python - "$OUT/bench_$f.log" <<'PY'
+import json,sys
+try:
+    r=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); s=r.get("single_gpu_same_job",{})
+    print("     same job on one GPU:", round(s.get("value",0),1), "G/s  speed-up", round(r.get("speedup_same_job",0),3), "efficiency", round(r.get("efficiency_same_job",0),3), s.get("error",""))
+except Exception as e: print("     FAILED", e)
+PY
+      done;;
+  emulate) timeout 1500 python scripts/scale_emulate.py --out "$OUT/scale_prediction.json" ${ARG:+--jobs $ARG} > "$OUT/scale_emulate.txt" 2>&1; grep -v amdgpu.ids "$OUT/scale_emulate.txt" | tail -24;;
+  benches)
+      for K in group scan asm simple refill; do b cfg2_$K --kernel $K --no-cpu-baseline --no-extras; done
+      b cfg2_cycle --opt cycle_detect=1 --no-cpu-baseline --no-extras
+      b cfg1 --workload cfg1 --no-cpu-baseline
+      b exterior --workload exterior --no-cpu-baseline; b exterior_both --workload exterior --outputs both --no-cpu-baseline
+      b chunk_l1 --workload chunk_l1 --no-cpu-baseline; b inset --workload inset --no-cpu-baseline
+      b cfg3 --workload cfg3; b cfg5 --workload cfg5; b cfg2_f32 --precision f32 --no-cpu-baseline
+      b cfg4_f32 --workload cfg4;;
+  ab) for rep in 1 2; do for W in cfg2 chunk_l1 cfg3; do
+        b ${W}_base_$rep --workload $W --no-cpu-baseline --no-extras
+        b ${W}_${ARG%%=*}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"
+      done; done;;
+  traces) for W in ${ARG:-cfg2 chunk_l1 cfg3 exterior}; do
+        case $W in cfg3) X="--steps 10 --warmup 2";; cfg4) X="--steps 2 --warmup 1";; *) X="";; esac
+        trace ${W}_default --workload $W --no-extras $X; done;;
+  pmc) C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+       C2="SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+       pmcrun cfg2_a "$C1" --steps 20 --warmup 5; pmcrun cfg2_b "$C2" --steps 20 --warmup 5
+       pmcrun cfg2_w "WRITE_SIZE" --steps 20 --warmup 5; pmcrun cfg2_f "FETCH_SIZE" --steps 20 --warmup 5
+       python scripts/pmc_summary.py "$OUT/cfg2_default_pmc_by_kernel.json" "$OUT/pmc_cfg2_a" "$OUT/pmc_cfg2_b" "$OUT/pmc_cfg2_w" "$OUT/pmc_cfg2_f" --match tile_
+       for W in ${ARG:-cfg3 chunk_l1}; do
+         case $W in cfg3) X="--steps 4 --warmup 1";; *) X="--steps 20 --warmup 5";; esac
+         pmcrun ${W}_a "$C1" --workload $W $X; pmcrun ${W}_b "$C2" --workload $W $X
+         python scripts/pmc_summary.py "$OUT/${W}_default_pmc_by_kernel.json" "$OUT/pmc_${W}_a" "$OUT/pmc_${W}_b" --match tile_
+       done
+       rm -rf "$OUT"/pmc_*_?;;
+  power) for spec in "cfg3 default 150" "inset default 600" "cfg2 default 4000"; do set -- $spec
+        timeout 300 python scripts/power_trace.py "$OUT/power_$1_$2.json" -- python bench.py --workload $1 --kernel $2 --no-cpu-baseline --no-extras --steps $3 --opt cycle_detect=0 > "$OUT/power_$1_$2.log" 2>&1
+        python - "$OUT/power_$1_$2.json" <<'PY'
+import json,sys
+try:
+    r=json.load(open(sys.argv[1])); print("  ", r["bench"]["workload"][:8], r["bench"]["kernel"], "cap", r.get("power_cap_W"), "busy W p50", r.get("busy_power_W",{}).get("p50"), "sclk p50", r.get("busy_sclk_MHz",{}).get("p50"), "J/Gpi", round(r.get("J_per_G_pixel_iteration",0),4), "G/s", round(r["bench"]["value"],1))
+except Exception as e: print("  power FAILED", e)
+PY
+      done;;
+  e2e) timeout 200 python scripts/level_rate.py 16 1024 > "$OUT/level16.log" 2>&1; grep "level\|two" "$OUT/level16.log"
+       timeout 900 python scripts/worker_e2e.py 12 256 3 > "$OUT/worker_e2e.log" 2>&1; grep -v amdgpu.ids "$OUT/worker_e2e.log" | tail -14;;
+  *) echo "unknown section $SEC";;
+  esac
+done
+du -sh "$OUT"

@@ -1,5 +1,6 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs per kernel: mean of every counter, dispatch count, and -- when the
-CSV carries Start/End timestamps -- the mean dispatch duration, the effective clock (GRBM_GUI_ACTIVE / duration),
+CSV carries Start/End timestamps -- the mean dispatch duration, the effective clock (GRBM_GUI_ACTIVE / 8 XCDs / duration:
+the counter is summed over the eight XCDs of an MI355X),
 VALU-busy (SQ_ACTIVE_INST_VALU x 4 / (SIMDs x GRBM_GUI_ACTIVE / 8)) and lane activity (SQ_THREAD_CYCLES_VALU / (64 x
 SQ_INSTS_VALU... in quad-cycle units: / (16 x SQ_ACTIVE_INST_VALU)).
     python scripts/pmc_summary.py out.json dir_or_csv [dir_or_csv ...] [--match substr]"""
@@ -38,7 +39,7 @@ for name, d in agg.items():
     dur = e.get("_duration_ns", {}).get("mean")
     act = e.get("SQ_ACTIVE_INST_VALU", {}).get("mean")
     if g and dur:
-        e["effective_clock_GHz"] = g / dur
+        e["effective_clock_GHz"] = g / 8.0 / dur   # GRBM_GUI_ACTIVE is the sum over the 8 XCDs (round 3 printed 18.3 "GHz")
     if g and act:
         e["valu_busy"] = act * 4.0 / (1024.0 * g / 8.0)
     thr, ins = e.get("SQ_THREAD_CYCLES_VALU", {}).get("mean"), e.get("SQ_INSTS_VALU", {}).get("mean")
