@@ -25,7 +25,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-struct Rec { unsigned long long cycles; unsigned hw_id, xcc_id; };
+struct Rec { unsigned long long t0, t1, r0, r1; unsigned hw_id, xcc_id; };   // s_memtime / s_memrealtime (100 MHz) at start and end
 
 // one step on the register set (ZR, ZI, A, B) with temporaries (T, P) and the constants (CR, CI)
 #define STEP(ZR, ZI, A, B, T, P, CR, CI)                  \
@@ -154,6 +154,7 @@ struct Rec { unsigned long long cycles; unsigned hw_id, xcc_id; };
 #define TIMED(PRE, BODY)                                   \
     PRE                                                    \
     "s_waitcnt lgkmcnt(0)\n"                               \
+    "s_memrealtime %[r0]\n"                                \
     "s_memtime %[t0]\n"                                    \
     "s_waitcnt lgkmcnt(0)\n"                               \
     ".Lloop_%=:\n"                                         \
@@ -162,6 +163,7 @@ struct Rec { unsigned long long cycles; unsigned hw_id, xcc_id; };
     "s_cmp_lg_u32 %[n], 0\n"                               \
     "s_cbranch_scc1 .Lloop_%=\n"                           \
     "s_memtime %[t1]\n"                                    \
+    "s_memrealtime %[r1]\n"                                \
     "s_waitcnt lgkmcnt(0)\n"
 
 enum Variant { V_PACKED, V_SPREAD, V_SAME, V_NOP, V_PROD, V_2PX, V_4PX, V_F32_E32, V_F32_E64, V_COUNT };
@@ -173,11 +175,11 @@ static const int kInstr[V_COUNT] = {96, 96, 96, 96, 2 * (96 + 2), 192, 384, 96, 
 template <int V>
 __global__ __launch_bounds__(64) void issue_kernel(Rec *out, double *sink, double cr_in, double ci_in, unsigned trips, unsigned prio)
 {
-    unsigned long long t0, t1;
+    unsigned long long t0, t1, r0, r1;
     unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)trips);
-    const unsigned long long crs = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(cr_in) & 0xffffffffll)) |
+    const unsigned long long crs = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(cr_in) & 0xffffffffll)) |
                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(cr_in) >> 32)) << 32);
-    const unsigned long long cis = (unsigned long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(ci_in) & 0xffffffffll)) |
+    const unsigned long long cis = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(ci_in) & 0xffffffffll)) |
                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(ci_in) >> 32)) << 32);
     if (prio == 1) {   // staggered priorities: wave slot parity decides (s_setprio takes an immediate)
         unsigned hw;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(64) void issue_kernel(Rec *out, double *sink, doubl
                            case 2: asm volatile("s_setprio 2"); break; default: asm volatile("s_setprio 3"); break; }
     }
     double res;
-#define OPERANDS_(CLOB) : [t0] "=&s"(t0), [t1] "=&s"(t1), [n] "+s"(n), [res] "=v"(res) : [crs] "s"(crs), [cis] "s"(cis) : "vcc", "scc", "memory", CLOB
+#define OPERANDS_(CLOB) : [t0] "=&s"(t0), [t1] "=&s"(t1), [r0] "=&s"(r0), [r1] "=&s"(r1), [n] "+s"(n), [res] "=v"(res) : [crs] "s"(crs), [cis] "s"(cis) : "vcc", "scc", "memory", CLOB
 #define OPERANDS OPERANDS_(CLOB32)
 #define OPERANDS_MULTI OPERANDS_(CLOB52)
     if (V == V_PACKED) {
@@ -231,14 +233,19 @@ __global__ __launch_bounds__(64) void issue_kernel(Rec *out, double *sink, doubl
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
     if (threadIdx.x == 0) {
-        out[blockIdx.x].cycles = t1 - t0;
+        out[blockIdx.x].t0 = t0;
+        out[blockIdx.x].t1 = t1;
+        out[blockIdx.x].r0 = r0;
+        out[blockIdx.x].r1 = r1;
         out[blockIdx.x].hw_id = hw_id;
         out[blockIdx.x].xcc_id = xcc_id;
     }
     sink[(size_t)blockIdx.x * 64 + threadIdx.x] = res;
 }
 
-struct Result { double cyc_per_simd_instr, cyc_per_wave_instr, ns_per_simd_instr, waves_med; int waves_min, waves_max; double mhz; };
+struct Result { double cyc_per_simd_instr, cyc_per_wave_instr, span_cyc_per_simd_instr, ns_per_simd_instr, waves_med, tick_mhz; int waves_min, waves_max; };
+
+static bool g_dump = false;   // print the (start, end) of the waves of one SIMD: do they run side by side or one pair after the other?
 
 template <int V>
 static Result run(int cus, int waves_per_simd, unsigned prio)
@@ -262,28 +269,56 @@ static Result run(int cus, int waves_per_simd, unsigned prio)
         h[rep].resize(nwaves);
         CHECK(hipMemcpy(h[rep].data(), d_rec, nwaves * sizeof(Rec), hipMemcpyDeviceToHost));
     }
-    // waves per SIMD from the placement census of the long run (key: XCC, and HW_ID without wave slot / pipe / queue bits)
+    // waves per SIMD from the placement census (key: XCC, and HW_ID without wave slot / pipe / queue bits)
     auto key = [](const Rec &r) { return ((unsigned long long)(r.xcc_id & 0xfu) << 32) | (r.hw_id & 0x0000ff30u); };
     std::map<unsigned long long, int> per_simd;
-    for (const Rec &r : h[1]) per_simd[key(r)]++;
-    std::vector<double> per_wave, per_simd_instr, wcount;
+    std::map<unsigned long long, std::pair<unsigned long long, unsigned long long>> span[2];   // first start, last end per SIMD
+    for (int rep = 0; rep < 2; ++rep)
+        for (const Rec &r : h[rep]) {
+            if (rep == 1) per_simd[key(r)]++;
+            auto it = span[rep].find(key(r));
+            if (it == span[rep].end()) span[rep][key(r)] = {r.t0, r.t1};
+            else { it->second.first = std::min(it->second.first, r.t0); it->second.second = std::max(it->second.second, r.t1); }
+        }
+    std::vector<double> per_wave, per_simd_instr, wcount, span_instr, mhz;
     const double d_instr = (double)(trips[1] - trips[0]) * kInstr[V];
     for (int w = 0; w < nwaves; ++w) {
-        const double slope = ((double)h[1][w].cycles - (double)h[0][w].cycles) / d_instr;
+        const double slope = ((double)(h[1][w].t1 - h[1][w].t0) - (double)(h[0][w].t1 - h[0][w].t0)) / d_instr;
         const int share = per_simd[key(h[1][w])];
         per_wave.push_back(slope);
         per_simd_instr.push_back(slope / share);
         wcount.push_back(share);
+        if (h[1][w].r1 > h[1][w].r0) mhz.push_back(100.0 * (double)(h[1][w].t1 - h[1][w].t0) / (double)(h[1][w].r1 - h[1][w].r0));
     }
-    auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    // per SIMD: (last end - first start) of the long run minus the same of the short run, over the instructions all its
+    // waves issued in between: shader cycles per SIMD-instruction whatever order the arbiter ran the waves in
+    for (auto &kv : span[1]) {
+        auto it = span[0].find(kv.first);
+        if (it == span[0].end() || per_simd[kv.first] == 0) continue;
+        const double d = (double)(kv.second.second - kv.second.first) - (double)(it->second.second - it->second.first);
+        span_instr.push_back(d / (d_instr * per_simd[kv.first]));
+    }
+    auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     Result r;
     r.cyc_per_wave_instr = med(per_wave);
     r.cyc_per_simd_instr = med(per_simd_instr);
+    r.span_cyc_per_simd_instr = med(span_instr);
     r.waves_med = med(wcount);
     r.waves_min = (int)*std::min_element(wcount.begin(), wcount.end());
     r.waves_max = (int)*std::max_element(wcount.begin(), wcount.end());
     r.ns_per_simd_instr = (ms[1] - ms[0]) * 1e6 / (d_instr * waves_per_simd);
-    r.mhz = r.ns_per_simd_instr > 0 ? 1e3 * (r.cyc_per_wave_instr / waves_per_simd) / r.ns_per_simd_instr : 0;
+    r.tick_mhz = med(mhz);
+    if (g_dump) {
+        const unsigned long long k0 = key(h[1][nwaves / 2]);
+        unsigned long long base = ~0ull;
+        for (const Rec &x : h[1]) if (key(x) == k0) base = std::min(base, x.t0);
+        printf("    the waves of one SIMD (long run), s_memtime ticks from the first start:");
+        std::vector<std::pair<unsigned long long, unsigned long long>> iv;
+        for (const Rec &x : h[1]) if (key(x) == k0) iv.push_back({x.t0 - base, x.t1 - base});
+        std::sort(iv.begin(), iv.end());
+        for (auto &p : iv) printf("  [%llu .. %llu]", p.first, p.second);
+        printf("\n");
+    }
     CHECK(hipFree(d_rec)); CHECK(hipFree(d_sink));
     CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
     return r;
@@ -292,14 +327,16 @@ static Result run(int cus, int waves_per_simd, unsigned prio)
 template <int V>
 static void report(int cus)
 {
-    for (int w : {8, 6, 4}) {
+    for (int w : {8, 6, 4, 2, 1}) {
         for (unsigned prio : {0u, 1u, 2u}) {
             if (prio != 0 && (w != 8 || (V != V_PACKED && V != V_PROD))) continue;
+            if (w < 4 && V != V_PACKED && V != V_PROD && V != V_4PX) continue;
+            g_dump = (V == V_PACKED || V == V_PROD) && prio == 0 && (w == 8 || w == 4);
             const Result r = run<V>(cus, w, prio);
-            printf("%-22s waves/SIMD %d (placed: median %.0f, min %d, max %d) setprio %s | %.3f cycles per SIMD-instr (s_memtime), %.2f per wave-instr | "
-                   "kernel-time slope %.3f ns per SIMD-instr => %.0f MHz\n",
-                   kNames[V], w, r.waves_med, r.waves_min, r.waves_max, prio == 0 ? "none" : prio == 1 ? "0/2 by slot parity" : "0..3 by slot", r.cyc_per_simd_instr,
-                   r.cyc_per_wave_instr, r.ns_per_simd_instr, r.mhz);
+            printf("%-22s waves/SIMD %d (placed: median %.0f, min %d, max %d) setprio %-18s | per wave %.2f ticks/instr | per SIMD (first start .. last end) "
+                   "%.3f ticks/instr | s_memtime ticks at %.0f MHz (vs s_memrealtime) | kernel-time slope %.3f ns per SIMD-instr\n",
+                   kNames[V], w, r.waves_med, r.waves_min, r.waves_max, prio == 0 ? "none" : prio == 1 ? "0/2 by slot parity" : "0..3 by slot",
+                   r.cyc_per_wave_instr, r.span_cyc_per_simd_instr, r.tick_mhz, r.ns_per_simd_instr);
             fflush(stdout);
         }
     }
