@@ -37,7 +37,7 @@ MBK_CODEC_RAW = 0x00
 MBK_CODEC_RLE = 0x01
 MBK_CHUNK_DEFINITION = 4096
 MBK_CHUNK_BYTES = 4096 * 4096
-MBK_ABI_VERSION = 3
+MBK_ABI_VERSION = 4
 
 
 class mbk_view(C.Structure):
@@ -64,7 +64,12 @@ class mbk_device_info(C.Structure):
 class mbk_worker_report(C.Structure):
     _fields_ = [("leased", C.c_uint64), ("accepted", C.c_uint64), ("rejected", C.c_uint64), ("resets", C.c_uint64),
                 ("uniform_tiles", C.c_uint64), ("pixel_iterations", C.c_uint64),
-                ("kernel_ms_sum", C.c_double), ("seconds", C.c_double)]
+                ("kernel_ms_sum", C.c_double), ("seconds", C.c_double), ("net_retries", C.c_uint64)]
+
+
+# enum mbk_net_option (include/mbk.h), in order: process-wide network behaviour of the native worker loop
+NET_OPTIONS = {name: i for i, name in enumerate(
+    ["max_connections", "connect_timeout_ms", "io_timeout_ms", "retries", "backoff_ms", "stop", "peak_connections"])}
 
 
 FEEDER_SUBMIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
@@ -119,6 +124,8 @@ SIGNATURES = {
                                     C.POINTER(mbk_stats)]),
     "mbk_worker_run": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint16, C.c_uint64, C.c_uint32,
                                  C.POINTER(mbk_worker_report)]),
+    "mbk_net_set_option": (C.c_int, [C.c_int, C.c_uint32]),
+    "mbk_net_get_option": (C.c_int, [C.c_int, C.POINTER(C.c_uint32)]),
     "mbk_feeder_run": (C.c_int, [C.POINTER(mbk_feeder_ops), C.c_char_p, C.c_uint16, C.c_uint64, C.c_uint32,
                                  C.POINTER(mbk_worker_report)]),
 }

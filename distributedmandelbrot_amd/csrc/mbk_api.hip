@@ -873,11 +873,24 @@ int mbk_create(int device, mbk_ctx **out)
                 MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fns[f][k], 64, 0));
                 ctx->scan_occ[f][k] = n > 0 ? n : 1;
             }
-        const void *fi[2] = {(const void *)mbk::tile_light_kernel<double, true, true, 2>, (const void *)mbk::tile_light_kernel<float, true, true, 2>};
+        // the finish-in-place launch is one of several instantiations (outputs x cycle test x fused statistics) with
+        // their own register counts: size the persistent grid for the least resident of them, or a launch whose
+        // instantiation holds fewer waves than assumed would run a second dispatch round
+        const void *fi[2][6] = {{(const void *)mbk::tile_light_kernel<double, true, true, 2>, (const void *)mbk::tile_light_kernel<double, true, true, 1>,
+                                 (const void *)mbk::tile_light_kernel<double, true, true, 2, true>, (const void *)mbk::tile_light_kernel<double, false, true, 2, true>,
+                                 (const void *)mbk::tile_light_kernel<double, true, false, 2, true>, (const void *)mbk::tile_light_kernel<double, true, false, 1>},
+                                {(const void *)mbk::tile_light_kernel<float, true, true, 2>, (const void *)mbk::tile_light_kernel<float, true, true, 1>,
+                                 (const void *)mbk::tile_light_kernel<float, true, true, 2, true>, (const void *)mbk::tile_light_kernel<float, false, true, 2, true>,
+                                 (const void *)mbk::tile_light_kernel<float, true, false, 2, true>, (const void *)mbk::tile_light_kernel<float, true, false, 1>}};
         for (int f = 0; f < 2; ++f) {
-            int n = 0;
-            MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fi[f], 64, 0));
-            ctx->scan_occ_inline[f] = n > 0 ? n : 1;
+            int least = 0;
+            for (int k = 0; k < 6; ++k) {
+                int n = 0;
+                MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fi[f][k], 64, 0));
+                n = n > 0 ? n : 1;
+                least = (k == 0 || n < least) ? n : least;
+            }
+            ctx->scan_occ_inline[f] = least;
         }
     }
 #undef MBK_CREATE_HIP
@@ -1316,6 +1329,54 @@ static void *ctx_alloc(void *user, uint64_t bytes)
     return mbk_host_alloc((mbk_ctx *)user, bytes, &p) == MBK_OK ? p : nullptr;
 }
 static void ctx_release(void *user, void *ptr) { (void)mbk_host_free((mbk_ctx *)user, ptr); }
+
+int mbk_net_set_option(int option, uint32_t value)
+{
+    mbkf::NetConfig &c = mbkf::net();
+    switch (option) {
+        case MBK_NET_MAX_CONNECTIONS:
+            if (value < 1u || value > 64u) return fail(nullptr, MBK_ERR_INVALID, "max connections must be in 1..64");
+            c.max_connections.store(value);
+            {
+                std::lock_guard<std::mutex> g(c.m);
+                c.peak = c.open;
+            }
+            c.cv.notify_all();
+            return MBK_OK;
+        case MBK_NET_CONNECT_TIMEOUT_MS: c.connect_timeout_ms.store(value); return MBK_OK;
+        case MBK_NET_IO_TIMEOUT_MS: c.io_timeout_ms.store(value); return MBK_OK;
+        case MBK_NET_RETRIES:
+            if (value > 100u) return fail(nullptr, MBK_ERR_INVALID, "retries must be in 0..100");
+            c.retries.store(value);
+            return MBK_OK;
+        case MBK_NET_BACKOFF_MS:
+            if (value < 1u || value > 10000u) return fail(nullptr, MBK_ERR_INVALID, "backoff must be in 1..10000 ms");
+            c.backoff_ms.store(value);
+            return MBK_OK;
+        case MBK_NET_STOP: c.stop.store(value ? 1u : 0u); return MBK_OK;
+        default: return fail(nullptr, MBK_ERR_INVALID, "unknown MBK_NET_* selector");
+    }
+}
+
+int mbk_net_get_option(int option, uint32_t *value)
+{
+    if (!value) return fail(nullptr, MBK_ERR_INVALID, "NULL argument");
+    mbkf::NetConfig &c = mbkf::net();
+    switch (option) {
+        case MBK_NET_MAX_CONNECTIONS: *value = c.max_connections.load(); return MBK_OK;
+        case MBK_NET_CONNECT_TIMEOUT_MS: *value = c.connect_timeout_ms.load(); return MBK_OK;
+        case MBK_NET_IO_TIMEOUT_MS: *value = c.io_timeout_ms.load(); return MBK_OK;
+        case MBK_NET_RETRIES: *value = c.retries.load(); return MBK_OK;
+        case MBK_NET_BACKOFF_MS: *value = c.backoff_ms.load(); return MBK_OK;
+        case MBK_NET_STOP: *value = c.stop.load(); return MBK_OK;
+        case MBK_NET_PEAK_CONNECTIONS: {
+            std::lock_guard<std::mutex> g(c.m);
+            *value = c.peak;
+            return MBK_OK;
+        }
+        default: return fail(nullptr, MBK_ERR_INVALID, "unknown MBK_NET_* selector");
+    }
+}
 
 int mbk_feeder_run(const mbk_feeder_ops *ops, const char *addr, uint16_t port, uint64_t max_tiles, uint32_t senders,
                    mbk_worker_report *report)

@@ -13,6 +13,13 @@ Wire protocol (Distributer.cs:30-45,358-458; DistributerWorkload.cs:53-100; all 
     response: C->S 0x01 + pack("IIII", level,mrd,indexReal,indexImag) ; S->C 0x20 | 0x21 ;
               on 0x20 C->S exactly 16 777 216 raw bytes (row = imaginary index, col = real index).
 
+Against the real server (round 4): the reference Distributer accepts on ONE thread with a listen backlog of 16
+(Distributer.cs:16,221,226-297) and 100 ms receive timeouts (:17,196-202); the reference worker held one connection
+at a time.  A farm must not bury it under 8 x (senders + 1) concurrent connects, and a computed tile must not be lost
+because one connect was refused: every connection here goes through a process-wide gate (`NET.max_connections`,
+default 8), has connect / IO timeouts, and both exchanges are retried with exponential backoff on transient failures
+until the server has answered (`set_network_options`; the native loop has the same knobs: mbk_net_set_option).
+
 Differences from the reference worker, all wire-compatible:
   * `sendall` / receive-exactly instead of bare `send` / `recv(4)` (WorkerCUDA.py:104-107,168 may
     transfer short; the bytes on the wire are identical when nothing is cut short);
@@ -100,12 +107,112 @@ def describe_stats(st) -> str:
             f"({rate:.0f} G/s reference-equivalent), {st.never_pixels} in-set pixels, stored as {kind}")
 
 
+class _Net:
+    """Process-wide network behaviour (the Python loops; `set_network_options` mirrors it into the native loop)."""
+    max_connections = 8          # < the reference's listenBacklog of 16 (Distributer.cs:16)
+    connect_timeout = 10.0       # seconds
+    io_timeout = 30.0            # per send / recv call without progress
+    retries = 6                  # attempts after the first, per exchange
+    backoff = 0.05               # first pause; doubles per attempt up to 2 s, plus jitter
+    retried = 0                  # exchanges repeated after a transient failure (diagnostic)
+    _gate = threading.BoundedSemaphore(8)
+
+
+NET = _Net
+
+
+def set_network_options(max_connections: Optional[int] = None, connect_timeout: Optional[float] = None,
+                        io_timeout: Optional[float] = None, retries: Optional[int] = None,
+                        backoff: Optional[float] = None, native: bool = True) -> None:
+    """Tune the connection gate, the timeouts and the retry policy of both worker loops (Python and, when the library
+    is built, native).  Call before starting a farm: resizing the gate while connections are open is not supported."""
+    if max_connections is not None:
+        if not 1 <= max_connections <= 64:
+            raise ValueError("max_connections must be in 1..64")
+        NET.max_connections = int(max_connections)
+        NET._gate = threading.BoundedSemaphore(NET.max_connections)
+    if connect_timeout is not None:
+        NET.connect_timeout = float(connect_timeout)
+    if io_timeout is not None:
+        NET.io_timeout = float(io_timeout)
+    if retries is not None:
+        NET.retries = int(retries)
+    if backoff is not None:
+        NET.backoff = float(backoff)
+    if native:
+        try:
+            from . import _lib as L
+            lib = L.load()
+        except (ImportError, OSError):
+            return
+        for name, value in (("max_connections", NET.max_connections), ("connect_timeout_ms", int(NET.connect_timeout * 1e3)),
+                            ("io_timeout_ms", int(NET.io_timeout * 1e3)), ("retries", NET.retries),
+                            ("backoff_ms", max(1, int(NET.backoff * 1e3)))):
+            if lib.mbk_net_set_option(L.NET_OPTIONS[name], value) != L.MBK_OK:
+                raise ValueError(f"native loop rejected {name} = {value}")
+
+
+def request_stop(stop: bool = True) -> None:
+    """Ask every running native loop (mbk_worker_run is one blocking C call per GPU) to stop leasing, return the tiles it
+    holds and end; the Python loops are interruptible between tiles anyway."""
+    from . import _lib as L
+    L.load().mbk_net_set_option(L.NET_OPTIONS["stop"], 1 if stop else 0)
+
+
+# "not now" rather than "never": the server's backlog was full (refused / reset), it was busy past a timeout, or it
+# closed before answering.  Anything else (e.g. an unknown reply code) is an error at once, as in the reference.
+_TRANSIENT = (ConnectionRefusedError, ConnectionResetError, ConnectionAbortedError, BrokenPipeError, socket.timeout,
+              TimeoutError, InterruptedError)
+
+
+class _PeerClosed(ConnectionError):
+    pass
+
+
+def _with_retries(exchange: Callable[[socket.socket], object], addr: str, port: int, timeout: Optional[float]):
+    """Run `exchange(sock)` on a fresh connection, through the connection gate; repeat it with exponential backoff while
+    it fails in a transient way BEFORE the server has answered (the exchange raises _Answered-wrapped errors itself
+    once it must not be repeated)."""
+    import random
+    last: Optional[BaseException] = None
+    for attempt in range(1 + max(0, NET.retries)):
+        if attempt:
+            pause = min(2.0, NET.backoff * (1 << min(attempt - 1, 6)))
+            time.sleep(pause + random.random() * pause / 2)
+            NET.retried += 1
+        gate = NET._gate
+        with gate:
+            try:
+                with socket.create_connection((addr, port), timeout=NET.connect_timeout if timeout is None else timeout) as sock:
+                    sock.settimeout(NET.io_timeout if timeout is None else timeout)
+                    return exchange(sock)
+            except _NoRetry as e:
+                raise e.inner from None
+            except (_PeerClosed,) + _TRANSIENT as e:
+                last = e
+            except OSError as e:
+                import errno
+                if e.errno not in (errno.EHOSTUNREACH, errno.ENETUNREACH, errno.EAGAIN, errno.ETIMEDOUT):
+                    raise
+                last = e
+    assert last is not None
+    raise last
+
+
+class _NoRetry(Exception):
+    """Wraps a failure that happened after the server answered: the exchange must not be repeated."""
+
+    def __init__(self, inner: BaseException):
+        super().__init__(str(inner))
+        self.inner = inner
+
+
 def _recv_exact(sock: socket.socket, n: int) -> bytes:
     buf = bytearray()
     while len(buf) < n:
         part = sock.recv(n - len(buf))
         if not part:
-            raise ConnectionError(f"connection closed after {len(buf)} of {n} bytes")
+            raise _PeerClosed(f"connection closed by peer after {len(buf)} of {n} bytes")
         buf += part
     return bytes(buf)
 
@@ -121,15 +228,20 @@ def receive_workload(sock: socket.socket) -> Workload:
 
 
 def request_workload(addr: str, port: int, timeout: Optional[float] = None) -> Optional[Workload]:
-    """First connection of WorkerCUDA.py:115-134.  None == 0x11 (no workload available)."""
-    with socket.create_connection((addr, port), timeout=timeout) as sock:
+    """First connection of WorkerCUDA.py:115-134.  None == 0x11 (no workload available).  A connect that is refused /
+    reset / times out, or a server that closes before its reply byte, is retried with backoff (NET.retries)."""
+    def exchange(sock: socket.socket):
         sock.sendall(struct.pack("B", REQUEST_CODE))
         response = _recv_exact(sock, 1)[0]
-        if response == WORKLOAD_AVAILABLE_CODE:
-            return receive_workload(sock)
-        if response == WORKLOAD_NOT_AVAILABLE_CODE:
-            return None
-        raise Exception("Unknown response code to request: " + str(response))  # WorkerCUDA.py:131-132
+        try:
+            if response == WORKLOAD_AVAILABLE_CODE:
+                return receive_workload(sock)      # the lease exists on the server now: never ask again for this one
+            if response == WORKLOAD_NOT_AVAILABLE_CODE:
+                return None
+            raise Exception("Unknown response code to request: " + str(response))  # WorkerCUDA.py:131-132
+        except BaseException as e:
+            raise _NoRetry(e)
+    return _with_retries(exchange, addr, port, timeout)
 
 
 SUBMIT_REJECTED, SUBMIT_ACCEPTED, SUBMIT_RESET = 0, 1, 2
@@ -150,31 +262,37 @@ def submit_workload_ex(addr: str, port: int, workload: Workload, out: np.ndarray
     payload = memoryview(np.ascontiguousarray(out, dtype=np.uint8)).cast("B")
     if len(payload) != CHUNK_BYTES:
         raise ValueError(f"tile payload must be {CHUNK_BYTES} bytes, got {len(payload)}")
-    with socket.create_connection((addr, port), timeout=timeout) as sock:
+    def exchange(sock: socket.socket) -> Tuple[int, int]:
         sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
         # one segment for opcode + header: the server reads them with separate 100 ms-timeout
         # receives (Distributer.cs:17,243-245,400), so do not dribble them
         sock.sendall(struct.pack("<BIIII", RESPONSE_CODE, *workload))
         response = _recv_exact(sock, 1)[0]
-        if response == WORKLOAD_REJECT_CODE:
-            _count("rejected")
-            return SUBMIT_REJECTED, 0
-        if response != WORKLOAD_ACCEPT_CODE:
-            raise Exception("Unknown response code to request: " + str(response))  # WorkerCUDA.py:165-166
-        sent = 0
+        # from here on the server has answered: nothing below may be repeated (on 0x20 it removed the lease,
+        # Distributer.cs:404-423)
         try:
-            while sent < CHUNK_BYTES:  # exactly 16 777 216 raw bytes, no header (WorkerCUDA.py:168)
-                sent += sock.send(payload[sent:])
-        except (ConnectionResetError, BrokenPipeError):
-            # The reference server reads the payload with ONE Socket.Receive (Distributer.cs:416) and
-            # then closes; with unread bytes in flight that close is a TCP reset.  By then it has
-            # already marked the tile completed (:422-423), and the reference worker's single
-            # `sock.send` never notices.  A server that died mid-transfer looks exactly the same from
-            # here, so the event is reported to the caller (and counted) instead of being swallowed.
-            _count("resets")
-            return SUBMIT_RESET, sent
-    _count("accepted")
-    return SUBMIT_ACCEPTED, sent
+            if response == WORKLOAD_REJECT_CODE:
+                _count("rejected")
+                return SUBMIT_REJECTED, 0
+            if response != WORKLOAD_ACCEPT_CODE:
+                raise Exception("Unknown response code to request: " + str(response))  # WorkerCUDA.py:165-166
+            sent = 0
+            try:
+                while sent < CHUNK_BYTES:  # exactly 16 777 216 raw bytes, no header (WorkerCUDA.py:168)
+                    sent += sock.send(payload[sent:])
+            except (ConnectionResetError, BrokenPipeError):
+                # The reference server reads the payload with ONE Socket.Receive (Distributer.cs:416) and
+                # then closes; with unread bytes in flight that close is a TCP reset.  By then it has
+                # already marked the tile completed (:422-423), and the reference worker's single
+                # `sock.send` never notices.  A server that died mid-transfer looks exactly the same from
+                # here, so the event is reported to the caller (and counted) instead of being swallowed.
+                _count("resets")
+                return SUBMIT_RESET, sent
+            _count("accepted")
+            return SUBMIT_ACCEPTED, sent
+        except BaseException as e:
+            raise _NoRetry(e)
+    return _with_retries(exchange, addr, port, timeout)
 
 
 def submit_workload(addr: str, port: int, workload: Workload, out: np.ndarray,
@@ -329,6 +447,8 @@ def run_native(addr: str, port: int, device_index: int = 0, log: Callable[..., N
     import ctypes as C
     from . import _lib as L
     from .device import MandelbrotDevice, MbkError
+    if max_tiles is not None and max_tiles <= 0:
+        return 0        # (mbk_worker_run reads 0 as "no limit": only None may map to it)
     own = device is None
     dev = device if device is not None else MandelbrotDevice(device_index)
     rep = L.mbk_worker_report()
@@ -342,7 +462,7 @@ def run_native(addr: str, port: int, device_index: int = 0, log: Callable[..., N
         log(f"native feeder: {rep.leased} tiles leased, {rep.accepted} accepted, {rep.rejected} rejected, {rep.resets} "
             f"reset after accept, {rep.uniform_tiles} uniform (not copied off the GPU); {rep.seconds:.3f} s = {rate:.1f} "
             f"tiles/s; kernel time {rep.kernel_ms_sum:.1f} ms; {rep.pixel_iterations / 1e9:.2f} G pixel-iterations "
-            "(reference-equivalent)")
+            f"(reference-equivalent); {rep.net_retries} exchange(s) repeated after a transient network failure")
         if st != L.MBK_OK:
             raise MbkError(st, (dev._lib.mbk_last_error(dev._h) or b"").decode())
         return int(rep.accepted + rep.resets)
@@ -409,6 +529,16 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
     return done
 
 
+_main_result: List[object] = []
+
+
+def _run_farm_catching(addr, port, devices, native):
+    try:
+        return run_farm(addr, port, devices, native=native, senders=4)
+    except BaseException as e:   # handed to the main thread
+        return e
+
+
 def main(argv: Optional[Sequence[str]] = None) -> None:
     """WorkerCUDA.py:178-184: prompts for the server address and port on stdin, then works until the
     server has nothing left.  Optional argv: ADDR PORT [gpu,gpu,...] to skip the prompts."""
@@ -422,7 +552,22 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     # every listed GPU gets its own pipelined feeder (an explicit single index -- `worker ADDR PORT 3` --
     # runs on THAT GPU; round 1 sent it to GPU 0); no list = every visible GPU, and run_farm raises when there is none.
     # The feeders are the native loop (mbk_worker_run); `worker ADDR PORT GPUS python` keeps the Python one.
-    run_farm(addr, port, devices, native=not (len(argv) >= 4 and argv[3] == "python"), senders=4)
+    # The native loop is one blocking C call per GPU: its sockets have timeouts (a dead server ends it with an error
+    # instead of hanging it), and Ctrl-C asks it to stop leasing and drain (mbk_net_set_option(MBK_NET_STOP)).
+    native = not (len(argv) >= 4 and argv[3] == "python")
+    farm = threading.Thread(target=lambda: _main_result.append(_run_farm_catching(addr, port, devices, native)), daemon=True)
+    _main_result.clear()
+    farm.start()
+    try:
+        while farm.is_alive():
+            farm.join(0.2)
+    except KeyboardInterrupt:
+        print("interrupt: finishing the tiles in flight, leasing no more")
+        if native:
+            request_stop()
+        farm.join()
+    if _main_result and isinstance(_main_result[0], BaseException):
+        raise _main_result[0]
     log_stats = dict(stats)
     print("tiles:", log_stats)
 

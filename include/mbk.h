@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MBK_ABI_VERSION 3
+#define MBK_ABI_VERSION 4
 
 /* DataChunk.cs:20 (dataChunkRange), WorkerCUDA.py:80 (definition = 4096). */
 #define MBK_CHUNK_DEFINITION 4096u
@@ -92,7 +92,10 @@ typedef struct mbk_view {
 } mbk_view;
 
 typedef struct mbk_stats {
-    float kernel_ms;           /* hipEvent time of the escape-time kernel launch(es) */
+    float kernel_ms;           /* hipEvent time of the escape-time kernel launch(es) on the slot's stream.  With
+                                  MBK_OPT_PREPASS_OVERLAP = 1 (the default) the dispatch-order pre-pass (~13 us: a fill +
+                                  classify_blocks_kernel) runs on an auxiliary stream beside the previous tile and is NOT
+                                  inside this interval unless the tile kernel had to wait for it; with 0 it is */
     float d2h_ms;              /* hipEvent time of the device->host copies */
     uint64_t pixel_iterations; /* sum over pixels of (count if count>0 else mrd-1), from the kernel's own counts: the
                                   REFERENCE's iterations for this output (with the cycle test on, fewer are executed) */
@@ -308,9 +311,35 @@ typedef struct mbk_worker_report {
     uint64_t pixel_iterations; /* reference-equivalent, summed over the tiles */
     double kernel_ms_sum;
     double seconds;            /* wall time of the call */
+    uint64_t net_retries;      /* exchanges that were repeated after a transient network failure (round 4, ABI 4) */
 } mbk_worker_report;
 int mbk_worker_run(mbk_ctx *ctx, const char *addr, uint16_t port, uint64_t max_tiles, uint32_t senders,
                    mbk_worker_report *report);
+
+/*
+ * Process-wide network behaviour of mbk_worker_run / mbk_feeder_run (every feeder of a farm shares it; round 4).  Why:
+ * the reference Distributer accepts on ONE thread, one connection at a time, with a listen backlog of 16
+ * (Distributer.cs:16,221,226-297) and 100 ms receive timeouts (:17,196-202), and the reference worker opened one
+ * connection at a time (WorkerCUDA.py:115,148).  8 feeders x (4 senders + 1 lease connection) must not present that
+ * server with 40 concurrent connects -- a full backlog is an RST on a Windows/.NET host -- and a computed tile must
+ * not be dropped because one connect failed.  Both exchanges are retried with exponential backoff on transient
+ * failures (refused, reset, timed out, closed before the reply) until the server has answered; after 0x20 the payload
+ * is sent once (the server removed the lease when it accepted, Distributer.cs:404-423).
+ */
+enum mbk_net_option {
+    MBK_NET_MAX_CONNECTIONS = 0,    /* connections open or being opened at any time, whole process; 1..64, default 8 */
+    MBK_NET_CONNECT_TIMEOUT_MS = 1, /* 0 = wait for ever; default 10 000 */
+    MBK_NET_IO_TIMEOUT_MS = 2,      /* per send / receive call without progress; 0 = none; default 30 000 */
+    MBK_NET_RETRIES = 3,            /* attempts after the first, per exchange; 0..100, default 6 */
+    MBK_NET_BACKOFF_MS = 4,         /* first pause; doubles per attempt up to 2 s, plus jitter; 1..10 000, default 50 */
+    MBK_NET_STOP = 5,               /* 1: every running loop stops leasing, returns the tiles it holds and ends (Ctrl-C
+                                       handlers set it from another thread); 0 re-arms */
+    MBK_NET_PEAK_CONNECTIONS = 6,   /* read-only (mbk_net_get_option): the most connections that were ever open at once;
+                                       setting MBK_NET_MAX_CONNECTIONS clears it */
+    MBK_NET_OPT_COUNT_
+};
+int mbk_net_set_option(int option, uint32_t value);
+int mbk_net_get_option(int option, uint32_t *value);
 
 /* The same protocol loop over a caller-supplied compute backend (mbk_worker_run is this with the backend bound to a
  * GPU context: submit = mbk_datachunk_submit_ex(MBK_LAZY_UNIFORM), wait = mbk_wait, alloc/release = pinned memory).

@@ -15,6 +15,13 @@ Restates the observable behaviour of Distributer.cs / DistributerWorkload.cs:
     the connection closed (:266-268).
 `faithful_single_receive=True` reproduces the reference defect of reading the payload with ONE
 Receive call (Distributer.cs:416) -- whatever arrives in that call is kept, the rest stays zero.
+
+"Reference-shaped" mode (round 4), for clients that open many connections at once: the loop is what the C# server's is
+-- ONE accept thread that handles a connection to its end before accepting the next (Distributer.cs:226-297),
+listen backlog 16 (:16,221) -- plus `receive_timeout=0.1` (the 100 ms ReceiveTimeout of :17,196-202),
+`payload_seconds` (a floor on the time a 16 MiB payload takes: the real server needs >= 10 ms) and `rst_every=k`:
+every k-th accepted connection is reset before a byte is read, which is what a client sees from a Windows/.NET host
+whose backlog is full (Linux would drop the SYN instead).  `accepted` counts accepts, `resets_sent` the resets.
 """
 from __future__ import annotations
 
@@ -32,11 +39,17 @@ Workload = Tuple[int, int, int, int]
 
 class FakeDistributer:
     def __init__(self, level_settings: List[Tuple[int, int]], lease_seconds: float = 3600.0,
-                 faithful_single_receive: bool = False, receive_timeout: Optional[float] = 5.0):
+                 faithful_single_receive: bool = False, receive_timeout: Optional[float] = 5.0,
+                 payload_seconds: float = 0.0, rst_every: int = 0):
         self.level_settings = list(level_settings)
         self.lease_seconds = lease_seconds
         self.faithful_single_receive = faithful_single_receive
         self.receive_timeout = receive_timeout
+        self.payload_seconds = payload_seconds
+        self.rst_every = rst_every
+        self.accepted = 0
+        self.resets_sent = 0
+        self.duplicate_completions = 0
         self.leases: List[Tuple[Workload, float]] = []
         self.completed: Dict[Workload, np.ndarray] = {}
         self.log: List[str] = []
@@ -110,6 +123,13 @@ class FakeDistributer:
             if self._stop:
                 c.close()
                 return
+            self.accepted += 1
+            if self.rst_every and self.accepted % self.rst_every == 0:
+                # what a full backlog looks like from a client of a Windows/.NET host: RST instead of SYN-ACK + service
+                c.setsockopt(socket.SOL_SOCKET, socket.SO_LINGER, struct.pack("ii", 1, 0))
+                c.close()
+                self.resets_sent += 1
+                continue
             c.settimeout(self.receive_timeout)
             try:
                 op = self._recv_exact(c, 1)[0]
@@ -148,7 +168,12 @@ class FakeDistributer:
             self.log.append(f"single receive got {got} bytes")
             payload = bytes(data)
         else:
+            t0 = time.monotonic()
             payload = self._recv_exact(c, CHUNK_BYTES)
+            if self.payload_seconds > 0:
+                time.sleep(max(0.0, self.payload_seconds - (time.monotonic() - t0)))
+        if w in self.completed:
+            self.duplicate_completions += 1
         for k, (lw, t) in enumerate(self.leases):
             if lw == w and now < t:
                 del self.leases[k]

@@ -4,6 +4,7 @@ default is the HIP path, which has no CPU fallback); here it is the CPU oracle o
 import socket
 import struct
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -453,3 +454,130 @@ def test_pipelined_worker_drains_inflight_tiles_when_the_lease_connection_fails(
             worker.request_workload = real
         assert srv.wait_completed(2) and len(dev.submitted) == 2
         assert all(p is None for p in dev.slots)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Round 4: the return path against a server shaped like the REAL one: one accept thread,
+# backlog 16, 100 ms receive timeouts, >= 10 ms per payload, resets when it is overrun.
+# ------------------------------------------------------------------------------------------------------
+
+def _net(name, value=None):
+    import ctypes as C
+    from distributedmandelbrot_amd import _lib as L
+    lib = L.load()
+    if value is None:
+        v = C.c_uint32(0)
+        assert lib.mbk_net_get_option(L.NET_OPTIONS[name], C.byref(v)) == 0
+        return v.value
+    assert lib.mbk_net_set_option(L.NET_OPTIONS[name], value) == 0
+
+
+def test_farm_of_native_feeders_against_a_reference_shaped_server():
+    """8 feeders x 4 senders (+ 8 lease connections) = up to 40 threads that want a connection, against ONE serial accept
+    loop with backlog 16 that resets every 7th connection: the process-wide gate keeps at most 8 connections open, a
+    reset exchange is repeated, and every tile is accepted exactly once with no lease left behind."""
+    _net("max_connections", 8)
+    _net("backoff_ms", 5)
+    try:
+        with FakeDistributer([(6, 16)], receive_timeout=0.1, payload_seconds=0.010, rst_every=7) as srv:
+            backends = [_NativeBackend() for _ in range(8)]
+            results = [None] * 8
+
+            def feeder(k):
+                results[k] = backends[k].run(srv.port, senders=4)
+            threads = [threading.Thread(target=feeder, args=(k,)) for k in range(8)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=120)
+            assert all(r is not None and r[0] == 0 for r in results), [r and (r[0], r[2]) for r in results]
+            assert srv.wait_completed(36)
+            reps = [r[1] for r in results]
+            assert sum(r.leased for r in reps) == 36 and sum(r.accepted for r in reps) == 36
+            assert sum(r.rejected for r in reps) == 0 and sum(r.resets for r in reps) == 0
+            assert sorted(w for be in backends for w in be.submitted) == sorted(srv.completed) and len(srv.completed) == 36
+            assert srv.duplicate_completions == 0 and not srv.leases and not srv.rejected      # no lease lost, none left
+            assert srv.resets_sent >= 5 and sum(r.net_retries for r in reps) == srv.resets_sent  # each reset cost one repeat
+            assert 1 <= _net("peak_connections") <= 8
+            for w, data in srv.completed.items():
+                assert np.array_equal(data, pattern_compute(*w))
+    finally:
+        _net("backoff_ms", 50)
+
+
+def test_native_feeder_times_out_on_a_server_that_accepts_and_never_answers():
+    """a server that accepts but never answers must end the call with MBK_ERR_NET, not hang it."""
+    srv_sock = socket.socket()
+    srv_sock.bind(("127.0.0.1", 0))
+    srv_sock.listen(4)
+    _net("io_timeout_ms", 200)
+    _net("retries", 1)
+    _net("backoff_ms", 5)
+    try:
+        t0 = time.monotonic()
+        rc, rep, err = _NativeBackend().run(srv_sock.getsockname()[1])
+        assert rc == 5 and rep.leased == 0 and rep.net_retries == 1 and time.monotonic() - t0 < 5.0
+        assert "workload request" in err and "Success" not in err, err
+    finally:
+        _net("io_timeout_ms", 30000)
+        _net("retries", 6)
+        _net("backoff_ms", 50)
+        srv_sock.close()
+    # a peer that closes before its reply is named as such (round 3 printed 'workload request: Success')
+    srv_sock = socket.socket()
+    srv_sock.bind(("127.0.0.1", 0))
+    srv_sock.listen(4)
+
+    def closer():
+        for _ in range(2):
+            c, _ = srv_sock.accept()
+            c.recv(1)
+            c.close()
+    th = threading.Thread(target=closer, daemon=True)
+    th.start()
+    _net("retries", 1)
+    _net("backoff_ms", 5)
+    try:
+        rc, rep, err = _NativeBackend().run(srv_sock.getsockname()[1])
+        assert rc == 5 and "connection closed by peer" in err, err
+    finally:
+        _net("retries", 6)
+        _net("backoff_ms", 50)
+        th.join(timeout=5)
+        srv_sock.close()
+
+
+def test_native_feeder_stop_flag_drains_and_ends():
+    with FakeDistributer([(3, 16)]) as srv:
+        be = _NativeBackend()
+        orig = be._wait
+        seen = {"n": 0}
+
+        def wait_then_stop(user, slot, stats):
+            seen["n"] += 1
+            if seen["n"] == 2:
+                _net("stop", 1)
+            return orig(user, slot, stats)
+        be.ops.wait = be.L.FEEDER_WAIT(wait_then_stop)
+        try:
+            rc, rep, err = be.run(srv.port)
+        finally:
+            _net("stop", 0)
+        assert rc == 0 and 2 <= rep.leased <= 4 and rep.accepted == rep.leased and srv.wait_completed(rep.leased), err
+        assert not srv.leases          # everything that was leased came back
+
+
+def test_python_worker_retries_a_reset_connection_and_gates_its_connections():
+    """The Python loops go through the same policy: connection gate, timeouts, retry with backoff until the server has
+    answered; run_native(max_tiles=0) leases nothing."""
+    old = (worker.NET.max_connections, worker.NET.backoff)
+    worker.set_network_options(max_connections=2, backoff=0.005, native=False)
+    try:
+        with FakeDistributer([(2, 16)], receive_timeout=0.1, rst_every=3) as srv:
+            before = worker.NET.retried
+            done = worker.run_farm("127.0.0.1", srv.port, devices=[0, 1, 2], make_compute=lambda d: pattern_compute, log=QUIET)
+            assert sum(done) == 4 and srv.wait_completed(4) and not srv.leases and not srv.rejected
+            assert srv.resets_sent >= 2 and worker.NET.retried - before == srv.resets_sent
+    finally:
+        worker.set_network_options(max_connections=old[0], backoff=old[1], native=False)
+    assert worker.run_native("127.0.0.1", 1, max_tiles=0, device=object()) == 0
