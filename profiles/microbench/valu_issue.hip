@@ -21,6 +21,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <string>
+#include <unistd.h>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -342,8 +344,58 @@ static void report(int cus)
     }
 }
 
-int main()
+// ---- clock probe: what does the shader clock do while ANOTHER process (bench.py) loads the chip? -------------------
+// One wave reads s_memtime (shader cycles) and s_memrealtime (100 MHz) ~100 us apart; the ratio is the shader clock
+// the wave lived through.  Run beside a benchmark:   /tmp/valu_issue --probe 8000 &  python bench.py ...
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, unsigned spins)
 {
+    unsigned long long t0, t1, r0, r1;
+    unsigned n = spins;
+    asm volatile("s_memrealtime %[r0]\n"
+                 "s_memtime %[t0]\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 ".Lspin_%=:\n"
+                 "s_sleep 127\n"
+                 "s_sub_u32 %[n], %[n], 1\n"
+                 "s_cmp_lg_u32 %[n], 0\n"
+                 "s_cbranch_scc1 .Lspin_%=\n"
+                 "s_memtime %[t1]\n"
+                 "s_memrealtime %[r1]\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 : [t0] "=&s"(t0), [t1] "=&s"(t1), [r0] "=&s"(r0), [r1] "=&s"(r1), [n] "+s"(n) : : "scc", "memory");
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
+static int probe(int total_ms)
+{
+    unsigned long long *d, h[2];
+    CHECK(hipMalloc(&d, 16));
+    hipStream_t s; CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    std::vector<double> mhz;
+    printf("# ms since start, shader clock MHz (s_memtime / s_memrealtime over the probe's life), probe kernel ms (launch to end: long = the chip was full)\n");
+    hipEvent_t start; CHECK(hipEventCreate(&start)); CHECK(hipEventRecord(start, s));
+    for (;;) {
+        CHECK(hipEventRecord(e0, s));
+        hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, d, 30u);
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s));
+        CHECK(hipStreamSynchronize(s));
+        float since = 0, dur = 0;
+        CHECK(hipEventElapsedTime(&since, start, e1));
+        CHECK(hipEventElapsedTime(&dur, e0, e1));
+        const double m = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+        printf("%8.1f %7.1f %6.3f\n", since, m, dur);
+        mhz.push_back(m);
+        if (since > total_ms) break;
+        usleep(8000);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 2 && std::string(argv[1]) == "--probe") return probe(atoi(argv[2]));
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     printf("device %s arch %s CUs %d clock %d MHz\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
     const int cus = prop.multiProcessorCount;

@@ -6,6 +6,7 @@
 #   tests        the whole `pytest -m gpu` suite            tests:EXPR  only tests matching -k EXPR
 #   soak[:S]     randomized parity soak for S seconds (default 120)
 #   issue        profiles/microbench/valu_issue.hip (fp64 issue rate in shader cycles)
+#   clock[:W:K ...]  the shader clock (s_memtime / s_memrealtime, a one-wave probe in a second process) while bench.py runs workload W for K steps
 #   headline     bench.py as the driver runs it
 #   n2           the N > 1 paths with two ranks on this box's one GPU (--oversubscribe; functional)
 #   emulate      scripts/scale_emulate.py -> scale_prediction.json
@@ -31,6 +32,21 @@ for SEC in "$@"; do
          else timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > "$OUT/pytest_gpu.txt" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest_gpu.txt"; grep -E "^FAILED|^ERROR" "$OUT/pytest_gpu.txt" | cut -c1-300 | head -10; fi;;
   soak) timeout 900 python scripts/gpu_soak.py ${ARG:-120} 17 > "$OUT/soak.txt" 2>&1; tail -2 "$OUT/soak.txt";;
   issue) hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue profiles/microbench/valu_issue.hip 2> "$OUT/build_issue.log" && timeout 300 /tmp/valu_issue > "$OUT/valu_issue.txt" 2>&1; cut -c1-200 "$OUT/valu_issue.txt";;
+  clock) hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue profiles/microbench/valu_issue.hip 2> "$OUT/build_issue.log"
+      for spec in ${ARG:-cfg2:4000 inset:700 cfg3:160 chunk_l1:6000}; do W=${spec%%:*}; K=${spec#*:}
+        /tmp/valu_issue --probe 9000 > "$OUT/clock_probe_$W.txt" 2>&1 &
+        PROBE=$!
+        sleep 1.5
+        timeout 300 python bench.py --workload $W --no-cpu-baseline --no-extras --steps $K --opt cycle_detect=0 > "$OUT/bench_clock_$W.log" 2>&1
+        wait $PROBE
+        line "$OUT/bench_clock_$W.log"
+        python - "$OUT/clock_probe_$W.txt" <<'PY'
+import sys
+rows=[l.split() for l in open(sys.argv[1]) if l[0] not in "#d"]
+rows=[(float(a),float(b),float(c)) for a,b,c in rows if len((a,b,c))==3]
+print("     t(ms):MHz:probe ms  " + "  ".join(f"{t:.0f}:{m:.0f}:{d:.2f}" for t,m,d in rows[::12]))
+PY
+      done;;
   headline) b cfg2_default;;
   n2) b queue_n1 --shard queue --no-cpu-baseline
       b queue_n2_oversub --gpus 2 --oversubscribe
