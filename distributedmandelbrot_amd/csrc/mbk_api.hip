@@ -86,6 +86,8 @@ struct mbk_ctx {
     uint32_t opt[MBK_OPT_COUNT_];    // tuning options (mbk_set_option); every value is bit-exact
     int scan_occ[2][2] = {{0, 0}, {0, 0}};  // resident single-wave workgroups per CU: [f64|f32][scan|heavy]
     int scan_occ_inline[2] = {0, 0};        // the same for pass 1 in its finish-in-place form (MBK_OPT_SCAN_INLINE)
+    uint32_t wave_limit_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MBK_OPT_WAVE_LIMIT: dynamic LDS bytes per single-wave workgroup
+                                            // that leave room for 4 x k workgroups per CU (k = index; 0 = no padding)
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -329,30 +331,32 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         a.ngrid = grid.x;
         a.order_mid = ctx->opt[MBK_OPT_PROBE_MID] <= probe_steps ? 1u : 0u;
     }
+    // MBK_OPT_WAVE_LIMIT: unused dynamic LDS caps the resident waves per SIMD (single-wave workgroups only)
+    const uint32_t lds = wpw == 1u ? ctx->wave_limit_lds[ctx->opt[MBK_OPT_WAVE_LIMIT] & 7u] : 0u;
     if (f32 && safe)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, lds, stream, a);
     else if (f32 && kernel == MBK_KERNEL_ASM)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 0>), grid, block, lds, stream, a);
     else if (f32 && cyc)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8, true>), grid, block, lds, stream, a);
     else if (f32)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8>), grid, block, lds, stream, a);
     else if (safe)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, false, 0>), grid, block, lds, stream, a);
     else if (kernel == MBK_KERNEL_ASM)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 0>), grid, block, lds, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 32 && !cyc)   // (with the cycle test 32 means 16: mbk_loops.inc)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 32>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 32>), grid, block, lds, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] >= 16 && cyc)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16, true>), grid, block, lds, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] >= 16)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16>), grid, block, lds, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 8 && cyc)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8, true>), grid, block, lds, stream, a);
     else if (ctx->opt[MBK_OPT_GROUP_STEPS] == 8)
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, lds, stream, a);
     else
-        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, lds, stream, a);
     MBK_HIP(ctx, hipGetLastError());
     if (order_slot >= 0) {   // list `order_slot` is busy until this tile kernel has finished
         MBK_HIP(ctx, hipEventRecord(order_sc->ev_done[order_slot], stream));
@@ -620,10 +624,11 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     s.hint_out = sc->h_hint;
     MBK_LAUNCH_LIGHT(0);
 #undef MBK_LAUNCH_LIGHT
+    const uint32_t lds2 = ctx->wave_limit_lds[ctx->opt[MBK_OPT_WAVE_LIMIT] & 7u];
     if (ctx->opt[MBK_OPT_CYCLE_DETECT] != 0u)
-        hipLaunchKernelGGL((mbk::tile_todo_kernel<T, true>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
+        hipLaunchKernelGGL((mbk::tile_todo_kernel<T, true>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), lds2, stream, a, s);
     else
-        hipLaunchKernelGGL((mbk::tile_todo_kernel<T, false>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), 0, stream, a, s);
+        hipLaunchKernelGGL((mbk::tile_todo_kernel<T, false>), dim3(mbk::kScanQueues * s.ranks2), dim3(64), lds2, stream, a, s);
     {
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
@@ -836,7 +841,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
-        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u};
+        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -891,6 +896,27 @@ int mbk_create(int device, mbk_ctx **out)
                 least = (k == 0 || n < least) ? n : least;
             }
             ctx->scan_occ_inline[f] = least;
+        }
+    }
+    {
+        // MBK_OPT_WAVE_LIMIT: the smallest dynamic-LDS size per workgroup at which the occupancy calculator admits no more
+        // than 4 k single-wave workgroups per CU (binary search on the runtime's own answer, no LDS granule assumed)
+        const void *fn = (const void *)mbk::tile_asm_kernel<double, true, 16, false>;
+        for (int k = 1; k <= 7; ++k) {
+            uint32_t lo = 0, hi = 65536;   // occ(lo) > 4k >= occ(hi)
+            int n = 0;
+            MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, hi));
+            if (n > 4 * k) {
+                ctx->wave_limit_lds[k] = hi;
+                continue;
+            }
+            while (hi - lo > 64) {
+                const uint32_t mid = (lo + hi) / 2;
+                MBK_CREATE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, mid));
+                if (n > 4 * k) lo = mid;
+                else hi = mid;
+            }
+            ctx->wave_limit_lds[k] = hi;
         }
     }
 #undef MBK_CREATE_HIP
@@ -1253,6 +1279,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_PREPASS_OVERLAP: ok = value <= 1u; break;
         case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
+        case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

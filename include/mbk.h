@@ -266,6 +266,11 @@ enum mbk_option {
                               all-exterior tile: 3 in 4 of a pyramid level), pass 1 finishes whatever blocks it cannot
                               finish in 4 steps itself, on the spot, stays in its block column, and pass 2 is not launched
                               (it cost 4.4 us to find empty lists): 0, [1] */
+    MBK_OPT_WAVE_LIMIT,    /* asm/group and scan pass 2: cap on the resident waves per SIMD of the one-wave-per-block kernels,
+                              imposed through unused dynamic LDS: [0] = none (8), 1..7.  Round 4 measured that the SIMD
+                              arbiter serves its OLDEST wave first and that 2-3 waves saturate the fp64 pipe
+                              (profiles/r04/valu_issue.txt): fewer resident waves shorten the drain at the end of a
+                              launch but leave fewer slots to hide the latency of light blocks */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

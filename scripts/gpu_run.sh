@@ -69,6 +69,11 @@ PY
       b chunk_l1 --workload chunk_l1 --no-cpu-baseline; b inset --workload inset --no-cpu-baseline
       b cfg3 --workload cfg3; b cfg5 --workload cfg5; b cfg2_f32 --precision f32 --no-cpu-baseline
       b cfg4_f32 --workload cfg4;;
+  wavelimit) # same-box sweep of MBK_OPT_WAVE_LIMIT (resident waves per SIMD of the one-wave-per-block kernels)
+      for W in exterior cfg2 chunk_l1 inset cfg3; do for L in 0 6 4 3 2 0; do
+        K=group; [ $W = cfg3 ] && X="--steps 12 --warmup 2" || X=""
+        b wl_${W}_$L --workload $W --kernel $K --no-cpu-baseline --no-extras --opt wave_limit=$L $X
+      done; done;;
   ab) for rep in 1 2; do for W in cfg2 chunk_l1 cfg3; do
         b ${W}_base_$rep --workload $W --no-cpu-baseline --no-extras
         b ${W}_${ARG%%=*}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"

@@ -407,6 +407,7 @@ OPTION_MATRIX = [
     ("group", {"group_steps": 32, "cycle_detect": 0}), ("group", {"group_steps": 32}), ("default", {"group_steps": 32, "cycle_detect": 0, "exact_long": 8}),
     ("scan", {"group_steps": 32, "cycle_detect": 0}),
     ("scan", {"scan_inline": 0}), ("default", {"scan_inline": 0, "cycle_detect": 0}), ("scan", {"scan_inline": 1, "scan_waves": 2, "cycle_detect": 0}),
+    ("group", {"wave_limit": 4}), ("scan", {"wave_limit": 2, "scan_inline": 0}), ("default", {"wave_limit": 7, "cycle_detect": 0}),
 ]
 
 
