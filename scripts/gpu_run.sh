@@ -74,6 +74,20 @@ PY
         K=group; [ $W = cfg3 ] && X="--steps 12 --warmup 2" || X=""
         b wl_${W}_$L --workload $W --kernel $K --no-cpu-baseline --no-extras --opt wave_limit=$L $X
       done; done;;
+  pmckernel) # PMC + trace of one kernel selector on one workload: pmckernel:KERNEL:WORKLOAD
+      K=${ARG%%:*}; W=${ARG#*:}
+      C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+      C2="SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+      trace ${W}_${K} --workload $W --kernel $K --no-extras
+      pmcrun ${W}_${K}_a "$C1" --workload $W --kernel $K --steps 20 --warmup 5; pmcrun ${W}_${K}_b "$C2" --workload $W --kernel $K --steps 20 --warmup 5
+      python scripts/pmc_summary.py "$OUT/${W}_${K}_pmc_by_kernel.json" "$OUT/pmc_${W}_${K}_a" "$OUT/pmc_${W}_${K}_b" --match tile_
+      rm -rf "$OUT"/pmc_*_?;;
+  wg4) for rep in 1 2; do
+        b cfg3_wg1_$rep --workload cfg3 --kernel group --no-cpu-baseline --no-extras --steps 12 --warmup 2
+        b cfg3_wg4_$rep --workload cfg3 --kernel group --no-cpu-baseline --no-extras --steps 12 --warmup 2 --opt waves_per_wg=4
+        b cfg2_wg1_$rep --kernel group --no-cpu-baseline --no-extras
+        b cfg2_wg4_$rep --kernel group --no-cpu-baseline --no-extras --opt waves_per_wg=4
+      done;;
   ab) for rep in 1 2; do for W in cfg2 chunk_l1 cfg3; do
         b ${W}_base_$rep --workload $W --no-cpu-baseline --no-extras
         b ${W}_${ARG%%=*}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"
