@@ -21,6 +21,7 @@
 #include "mbk_refill.h"
 #include "mbk_persist.h"
 #include "mbk_scan.h"
+#include "mbk_units.h"
 #include "mbk_feeder.h"
 
 using mbk::Axis;
@@ -261,6 +262,7 @@ static int get_scratch(mbk_ctx *ctx, hipStream_t stream, StreamScratch **out)
 //   ring_possible               conservative rectangle test against | |c|^2 - 4 | < margin (kernel margins are
 //                               1e-9 fp64 / 1e-3 fp32 per pixel; the host test allows 1e-6 / 2e-3).
 static void set_window_facts(TileArgs &a, bool f32);
+static double window_heavy_share(const TileArgs &a);
 
 // Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
 // (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
@@ -277,7 +279,12 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     a.order = nullptr;
     int order_slot = -1;
     StreamScratch *order_sc = nullptr;
-    if (order_mode == 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps && a.blocks_x <= 0xffffu && by <= 0xffffu) {
+    // order 3 = "units" (mbk_units.h): the light blocks of eight neighbouring block columns are ONE workgroup.  Where the
+    // units kernel cannot serve a launch (outputs, widths, step counts it has no form for) the launch takes order 2.
+    const bool units = order_mode == 3 && wpw == 1u && kernel == MBK_KERNEL_GROUP && !safe && a.smooth == nullptr &&
+                       (a.counts || a.bytes) && !(a.bytes && a.quant_wide) && a.blocks_x % 8u == 0u && a.blocks_x <= 2048u &&
+                       a.fast_bx_end > 0u && a.fast_by_end > 0u && (f32 || ctx->opt[MBK_OPT_GROUP_STEPS] == 16u);
+    if (order_mode >= 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps && a.blocks_x <= 0xffffu && by <= 0xffffu) {
         // (a list entry packs block row and workgroup column into 16 bits each; wider windows go in image order)
         // heavy-first dispatch order (see classify_blocks_kernel); small launches skip it: one kernel in image
         // order beats memset + classify + tile below ~16 k blocks (cfg1, 4096 blocks: 20 us against 27)
@@ -319,6 +326,10 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         if (overlap && sc->done_valid[k]) MBK_HIP(ctx, hipStreamWaitEvent(sc->aux, sc->ev_done[k], 0));
         // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
+        if (units)
+            hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a, grid.x,
+                               (int32_t)probe_steps, ord, cursors);
+        else
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a,
                            grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
         if (overlap) {
@@ -333,6 +344,35 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     }
     // MBK_OPT_WAVE_LIMIT: unused dynamic LDS caps the resident waves per SIMD (single-wave workgroups only)
     const uint32_t lds = wpw == 1u ? ctx->wave_limit_lds[ctx->opt[MBK_OPT_WAVE_LIMIT] & 7u] : 0u;
+    if (units && a.order) {
+        // Grid: the host cannot know how many units the probe makes of this window, so it estimates them from its own
+        // 16 x 16 probe (share of the pixels still inside after 4 steps ~ the H and M blocks; the rest, eight to a unit)
+        // and the kernel strides: a deterministic function of the window, no hint from earlier launches.
+        const double share = window_heavy_share(a);
+        const double est = (double)grid.x * (share + (1.0 - share) / 8.0);
+        const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+        uint32_t g = (uint32_t)std::min<double>((double)grid.x, est * 1.15 + 2048.0);
+        g = std::max(g, std::min(grid.x, cus * 64u));
+        a.unit_stride = g;
+        uint32_t qtab = 0u;   // quantised bytes of counts 1..4, packed (the light path's table)
+        if (a.bytes && a.mrd > 0)
+            for (uint32_t c = 1; c <= 4u; ++c)
+                qtab |= (uint32_t)(((uint64_t)c * 256u + (uint32_t)a.mrd - 1u) / (uint32_t)a.mrd & 0xffu) << (8u * (c - 1u));
+#define MBK_LAUNCH_UNITS(T, G, CYC)                                                                                         \
+    do {                                                                                                                   \
+        if (a.counts && a.bytes)                                                                                           \
+            hipLaunchKernelGGL((mbk::tile_units_kernel<T, G, CYC, true, true>), dim3(g), dim3(64), lds, stream, a, qtab);   \
+        else if (a.bytes)                                                                                                  \
+            hipLaunchKernelGGL((mbk::tile_units_kernel<T, G, CYC, false, true>), dim3(g), dim3(64), lds, stream, a, qtab);  \
+        else                                                                                                               \
+            hipLaunchKernelGGL((mbk::tile_units_kernel<T, G, CYC, true, false>), dim3(g), dim3(64), lds, stream, a, qtab);  \
+    } while (0)
+        if (f32 && cyc) MBK_LAUNCH_UNITS(float, 8, true);
+        else if (f32) MBK_LAUNCH_UNITS(float, 8, false);
+        else if (cyc) MBK_LAUNCH_UNITS(double, 16, true);
+        else MBK_LAUNCH_UNITS(double, 16, false);
+#undef MBK_LAUNCH_UNITS
+    } else
     if (f32 && safe)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, lds, stream, a);
     else if (f32 && kernel == MBK_KERNEL_ASM)
@@ -1261,7 +1301,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
     if (!ctx) return fail(ctx, MBK_ERR_INVALID, "ctx is NULL");
     bool ok = false;
     switch (option) {
-        case MBK_OPT_ORDER: ok = value <= 2u; break;
+        case MBK_OPT_ORDER: ok = value <= 3u; break;
         case MBK_OPT_WAVES_PER_WG: ok = value == 1u || value == 2u || value == 4u; break;
         case MBK_OPT_GROUP_STEPS: ok = value == 4u || value == 8u || value == 16u || value == 32u; break;
         case MBK_OPT_EXACT_STEPS: ok = value <= 4096u; break;

@@ -58,6 +58,7 @@ struct TileArgs {
                            // when both fit 16 bits
     uint32_t ngrid;        // with `order`: the grid size (= list length); the counters sit at order[ngrid .. ngrid + 3)
     uint32_t order_mid;    // with `order`: 1 = a middle class was built (MBK_OPT_PROBE_MID <= probe depth)
+    uint32_t unit_stride;  // kernel "units" (mbk_units.h): the grid size G; workgroup j takes units j, j + G, ...
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
     double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value
@@ -171,23 +172,27 @@ __global__ __launch_bounds__(256) void tile_simple_kernel(TileArgs p)
 #define MBK_T double
 #define MBK_F "f64"
 #define MBK_CI_FROM_T64 "v_add_f64 %[ci], %[t64], %[start]\n"
+#define MBK_CR_FROM_T64 "v_add_f64 %[cr], %[t64], %[start]\n"
 #define MBK_CYC_BITS "u64"   // bitwise state compare / copy of the cycle test
 #define MBK_CYC_MOV "b64"
 #include "mbk_loops.inc"
 #undef MBK_T
 #undef MBK_F
 #undef MBK_CI_FROM_T64
+#undef MBK_CR_FROM_T64
 #undef MBK_CYC_BITS
 #undef MBK_CYC_MOV
 #define MBK_T float
 #define MBK_F "f32"
 #define MBK_CI_FROM_T64 "v_add_f64 %[t64], %[t64], %[start]\nv_cvt_f32_f64 %[ci], %[t64]\n"
+#define MBK_CR_FROM_T64 "v_add_f64 %[t64], %[t64], %[start]\nv_cvt_f32_f64 %[cr], %[t64]\n"
 #define MBK_CYC_BITS "u32"
 #define MBK_CYC_MOV "b32"
 #include "mbk_loops.inc"
 #undef MBK_T
 #undef MBK_F
 #undef MBK_CI_FROM_T64
+#undef MBK_CR_FROM_T64
 #undef MBK_CYC_BITS
 #undef MBK_CYC_MOV
 

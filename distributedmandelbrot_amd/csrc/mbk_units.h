@@ -1,0 +1,130 @@
+// mbk_units.h -- kernel "group" with UNITS (round 4): the dispatch order of the one-wave-per-block kernel, rebuilt on what
+// round 4 measured about the chip.
+//
+// Facts (profiles/r04/NOTES.md; valu_issue.txt, the wave_limit sweep, scripts/fifo_model.py):
+//   * a SIMD's arbiter serves its OLDEST wave first, and two or three waves saturate the fp64 pipe at 4.04-4.06 shader
+//     cycles per instruction -- there is no issue gap to recover inside the loops;
+//   * the chip has ONE workgroup dispatcher, 0.28 ns per single-wave workgroup, in list order, and a block that is gone
+//     after a few steps lives ~1 us (launch, two scalar round trips, ~60 vector instructions of set-up, stores);
+//   * so a cfg2 launch (262 144 blocks, 167 000 of them gone within 3 steps) ends with a ~50 us phase in which the
+//     dispatcher deals out light blocks one by one while the last heavy waves drain: 8 % of the launch, 12 % on the
+//     DataChunk (1,0,0) tile.  An event model with those three facts reproduces the measured launches (cfg2 544.5 vs 547 us,
+//     chunk_l1 335.7 vs 336 us, round 3's three-class experiment +0.9 % vs +0.7 %) and predicts -5.6 % / -11.5 % for the
+//     order built here.
+//
+// Three classes from the one-pixel probe of classify (centre pixel of every 8x8 block, 32 steps):
+//   H  the probe did not escape        -> one workgroup per block, 16-step groups          (front of the list)
+//   M  it escaped at step 4..31, or the block touches a ragged edge / a pinned end point
+//                                      -> one workgroup per block, 8-step groups           (list of its own)
+//   V  it escaped within 3 steps       -> ROW UNITS: the V blocks of an aligned group of 8 block columns of one block row
+//                                         are ONE workgroup, which runs them through the light path (four steps of the
+//                                         reference loop with the reference's own test, mbk_loops.inc: escape_light_row)
+//                                         and finishes in place, with the code of H/M, whatever block that path cannot.
+// Dispatch order H, M, V: the longest jobs first, the boundary blocks next (they used to be filed under "light" and
+// dispatched last: round 3's middle class pulled them forward and LOST, because it left 200 000 single light blocks as
+// a dispatch-bound tail -- here that tail is 21 000 units), the units last, as the filler of the drain.
+// The host cannot know how many units the probe will produce, so the grid is an estimate from its own 256-pixel probe of
+// the window and workgroup j takes units j, j + G, j + 2G ... : too small a grid costs a second trip for some workgroups,
+// too large a few that leave after one load.  A scheduling heuristic throughout: which class a block lands in changes
+// when it is computed and by which of two exact routines, never what is stored.
+#pragma once
+
+#include "mbk_refill.h"  // uniform_u32/u64 (includes mbk_kernels.h)
+
+namespace mbk {
+
+// Layout of the list (same buffer as classify_blocks_kernel's): order[0 .. n) H entries from the front and V units from
+// the back, order[n .. n+3) the counters (H, V units, M), order[n+3 .. 2n+3) the M entries.  H / M entry: (block row << 16)
+// | block column.  V unit: (block row << 16) | (first block column / 8) << 8 | mask of the V blocks among its 8 columns.
+// Needs blocks_x % 8 == 0 (a unit never wraps a row), blocks_x <= 2048, block rows < 65536 (the host checks).
+__global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
+                                                              uint32_t *order, uint32_t *counters)
+{
+    __shared__ uint32_t s_cnt[3][16], s_base[3];
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool valid = r < nregions;
+    uint32_t cls = 3u;     // 0 H, 1 V, 2 M, 3 nothing
+    uint32_t by = 0, bx = 0;
+    if (valid) {
+        by = r / p.blocks_x;
+        bx = r - by * p.blocks_x;
+        uint32_t lc = bx * 8u + 4u, lr = by * 8u + 4u;
+        lc = lc < p.ncols ? lc : p.ncols - 1u;
+        lr = lr < p.nrows ? lr : p.nrows - 1u;
+        const double cr = axis_value(p.re, p.col0 + lc), ci = axis_value(p.im, p.row0 + lr);
+        const int32_t cap = p.mrd < probe_steps ? p.mrd : probe_steps;
+        const int32_t cnt = cap > 1 ? escape_count<true>(cr, ci, cap) : 1;
+        const bool regular = bx < p.fast_bx_end && by < p.fast_by_end;   // the light path's coordinates are the regular formula
+        cls = cnt == 0 ? 0u : (cnt <= 3 && regular ? 1u : 2u);
+    }
+    // V blocks -> one unit per aligned group of 8 lanes (= 8 block columns of one row: blocks_x % 8 == 0 and the workgroup's
+    // first region is a multiple of 8)
+    const unsigned long long vmask = __ballot(cls == 1u);
+    const uint32_t seg = (uint32_t)(vmask >> (lane & ~7u)) & 0xffu;
+    const bool emit[3] = {cls == 0u, (lane & 7u) == 0u && seg != 0u, cls == 2u};
+    unsigned long long m[3];
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        m[k] = __ballot(emit[k]);
+        if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(m[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        const uint32_t k = threadIdx.x, nw = (blockDim.x + 63u) >> 6;
+        uint32_t t = 0;
+        for (uint32_t w = 0; w < nw; ++w) {
+            const uint32_t c = s_cnt[k][w];
+            s_cnt[k][w] = t;
+            t += c;
+        }
+        s_base[k] = t ? atomicAdd(&counters[k], t) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (emit[0]) order[s_base[0] + s_cnt[0][wave] + (uint32_t)__popcll(m[0] & below)] = (by << 16) | bx;
+    if (emit[1]) order[nregions - 1u - (s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(m[1] & below))] = (by << 16) | ((bx >> 3) << 8) | seg;
+    if (emit[2]) order[nregions + 3u + s_base[2] + s_cnt[2][wave] + (uint32_t)__popcll(m[2] & below)] = (by << 16) | bx;
+}
+
+// Workgroup j: units j, j + G, ... (G = p.unit_stride: the grid size, passed as an argument -- gridDim.x lives in the
+// dispatch packet in host memory and would be re-read on every trip).  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
+template <typename T, int kGroup, bool kCycle, bool kCounts, bool kBytes>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_units_kernel(TileArgs p, uint32_t qtab)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t n = p.ngrid;
+    const uint32_t n_h = uniform_u32(p.order[n]), n_v = uniform_u32(p.order[n + 1u]), n_m = uniform_u32(p.order[n + 2u]);
+    const uint32_t total = n_h + n_m + n_v;
+    const uint32_t oscale = kCounts ? 4u : 1u;
+    for (uint32_t u = blockIdx.x; u < total; u += p.unit_stride) {
+        if (u < n_h + n_m) {
+            const bool is_h = u < n_h;
+            // (loads inside the loop follow this wave's own stores, so the compiler will not keep them on the scalar unit
+            // by itself; the address is wave-uniform: say so)
+            const uint32_t e = uniform_u32(is_h ? p.order[u] : p.order[n + 3u + (u - n_h)]);
+            const uint32_t by = e >> 16, bx = e & 0xffffu;
+            block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h, bx < p.fast_bx_end && by < p.fast_by_end);
+        } else {
+            const uint32_t v = uniform_u32(p.order[n - 1u - (u - n_h - n_m)]);
+            const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
+            // the unit's imaginary coordinate (regular formula: classify files under V only blocks inside the fast region)
+            const T ci = (T)((double)(p.row0 + by * 8u + ly) * p.im.step + p.im.start);
+            const T b0 = ci * ci;
+            const size_t elem0 = (size_t)(by * 8u + p.out_row0) * p.out_pitch + bx0 * 8u + p.out_col0;
+            int32_t *cb = reinterpret_cast<int32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(kCounts ? p.counts + elem0 : nullptr)));
+            uint8_t *bb = reinterpret_cast<uint8_t *>(uniform_u64(reinterpret_cast<unsigned long long>(kBytes ? p.bytes + elem0 : nullptr)));
+            const uint32_t col = p.col0 + bx0 * 8u + lx, off = (ly * p.out_pitch + lx) * oscale;
+            uint32_t k = 0;
+            int32_t cnt;
+            while (escape_light_row<kCounts, kBytes>(ci, b0, col, p.re.step, p.re.start, cnt, cb, bb, off, 8u * oscale, qtab, mask, k) != 0u) {
+                // block k of the unit outlives the light path (the probe saw only its centre pixel): the whole block, exactly
+                block_pixel<T, true, kGroup, kCycle>(p, (bx0 + k) * 8u, by * 8u, lx, ly, false, true);
+                if (++k >= 8u) break;
+            }
+        }
+    }
+}
+
+}  // namespace mbk

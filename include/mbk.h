@@ -229,8 +229,12 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
  * range.  Defaults in brackets.
  */
 enum mbk_option {
-    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, [2] heavy-first list
-                              (probe never escaped first; optionally a middle class, MBK_OPT_PROBE_MID) */
+    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, 2 heavy-first list
+                              (probe never escaped first; optionally a middle class, MBK_OPT_PROBE_MID), 3 "units" (round 4,
+                              csrc/mbk_units.h): probe never escaped / escaped at step 4..31 one workgroup per block in that
+                              order, then the blocks whose probe escaped within 3 steps eight block columns to a workgroup
+                              through the light path; launches it has no form for (kernel "asm", smooth output, 64-bit
+                              quantiser, block columns not a multiple of 8 or > 2048, group_steps != 16) take order 2 */
     MBK_OPT_WAVES_PER_WG,  /* asm/group: 8x8 blocks per workgroup: [1], 2, 4 */
     MBK_OPT_GROUP_STEPS,   /* group: steps per grouped bailout test: 4, 8, [16], 32 (16 / 32 apply to the blocks classified as
                               interior -- probe-heavy / dense --, the rest keep 8).  Scan pass 2 and the fp32 loops have no

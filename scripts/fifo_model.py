@@ -190,3 +190,21 @@ if args.light_k:
     grouped = np.concatenate([li, np.zeros(pad)]).reshape(-1, k).sum(1) + 40.0
     report(f"heavy first, light blocks {k} per workgroup", np.concatenate([instr[h], grouped]))
     report(f"heavy longest first, light blocks {k} per workgroup", np.concatenate([np.sort(instr[h])[::-1], grouped]))
+
+# ---- "units" design (round 4 study): heavy blocks and boundary blocks one per workgroup, VERY light blocks (centre pixel gone
+# within 3 steps) in runs of K per workgroup through the light path (18.5 instructions per block that four steps finish; a
+# block of the run that they do not finish is finished in place at the price of a whole block)
+vl = (~heavy) & (center >= 1) & (center <= 3)
+mid = (~heavy) & ~vl
+for k in (4, 8, 16):
+    li = np.where(last[idx[vl]] <= 4, 18.5, instr[idx[vl]] + 20.0)
+    pad = (-len(li)) % k
+    runs = np.concatenate([li, np.zeros(pad)]).reshape(-1, k).sum(1) + 40.0
+    report(f"units: heavy, boundary singles, very light in runs of {k}", np.concatenate([instr[h], instr[idx[mid]], runs]))
+    report(f"units: heavy, runs of {k} interleaved with boundary singles",
+           np.concatenate([instr[h], np.random.RandomState(1).permutation(np.concatenate([instr[idx[mid]], runs]))]))
+print("classes: heavy", int(heavy.sum()), "boundary (centre gone at step 4..31)", int(mid.sum()), "very light", int(vl.sum()),
+      "of which finished by 4 steps", int((last[idx[vl]] <= 4).sum()))
+# round 3's measured experiment, for calibration: three classes of SINGLE blocks (heavy / probe count >= 6 / rest): measured +0.7 % slower than two classes
+mid6 = (~heavy) & (center >= 6)
+report("r3 experiment: heavy, probe count >= 6 singles, light singles", np.concatenate([instr[h], instr[idx[mid6]], instr[idx[(~heavy) & ~mid6]][::-1]]))

@@ -408,6 +408,8 @@ OPTION_MATRIX = [
     ("scan", {"group_steps": 32, "cycle_detect": 0}),
     ("scan", {"scan_inline": 0}), ("default", {"scan_inline": 0, "cycle_detect": 0}), ("scan", {"scan_inline": 1, "scan_waves": 2, "cycle_detect": 0}),
     ("group", {"wave_limit": 4}), ("scan", {"wave_limit": 2, "scan_inline": 0}), ("default", {"wave_limit": 7, "cycle_detect": 0}),
+    ("group", {"order": 3}), ("group", {"order": 3, "cycle_detect": 0}), ("default", {"order": 3, "exact_steps": 3, "probe_steps": 8}),
+    ("group", {"order": 2}), ("group", {"order": 3, "group_steps": 8}), ("group", {"order": 3, "waves_per_wg": 2}),
 ]
 
 
@@ -434,6 +436,50 @@ def test_option_matrix_is_bit_exact(oracle, kernel, options):
             dev.set_option("scan_waves", 9)
         for view, mrd in cases:
             _check_view(dev, oracle, view, mrd, kernel=kernel)
+
+
+def test_units_order_every_output_set_and_shape(oracle):
+    """Order 3 ("units", csrc/mbk_units.h): the light blocks of eight block columns are one workgroup that runs them through
+    the light path.  Every output instantiation (counts / bytes / both) x fp64 / fp32 x cycle test on / off through
+    mbk_view_launch on device buffers, on views that exercise what the unit path must get right: rows that are no multiple
+    of 8 and a window that stops short of the view (ragged edges -> class M), a window with an offset into a larger view,
+    units in which the probe misses a long-lived block (the antenna: y = 0 midway between two probe rows), a tile with no
+    set in it, a tile that is all set, and mrd at the light path's step limits."""
+    import torch
+    from distributedmandelbrot_amd import MandelbrotDevice
+    cases = [
+        (View(-2.0, -1.5, 3.0, 3.0, 2048, 2048), None, 300),
+        (View(-2.0, -1.5, 3.0, 3.0, 2048, 1203), None, 200),                      # ragged last block row
+        (View(-2.0, -2.0, 4.0, 4.0, 4096, 4096), (512, 1024, 2048, 1024), 150),   # a window inside a larger view
+        (View(-2.0, -0.0125, 1.75, 0.025, 4096, 1027), None, 400),                # the antenna between probe rows
+        (View(-2.0, -2.0, 1.0, 1.0, 2048, 1024), None, 1000),                     # all exterior: V units only
+        (View(-0.2, -0.1, 0.2, 0.2, 1024, 1024), None, 120),                      # all interior: H only
+        (View(-0.755, 0.10, 0.02, 0.02, 1024, 1024), None, 70),                   # boundary-rich: mostly M
+        (View(-2.0, -1.5, 3.0, 3.0, 1536, 1024), None, 66),                       # mrd just above the 2 x probe depth gate
+    ]
+    with MandelbrotDevice(0) as dev:
+        dev.set_option("order", 3)
+        for cyc in (1, 0):
+            dev.set_option("cycle_detect", cyc)
+            for view, window, mrd in cases:
+                col0, row0, ncols, nrows = window if window else (0, 0, view.width, view.height)
+                for precision in ("f64", "f32"):
+                    oc, ob, _ = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd,
+                                            window=window, precision=precision)
+                    for want_c, want_b in ((True, False), (False, True), (True, True)):
+                        dc = torch.full((nrows * ncols,), -9, dtype=torch.int32, device="cuda:0") if want_c else None
+                        db = torch.full((nrows * ncols,), 77, dtype=torch.uint8, device="cuda:0") if want_b else None
+                        torch.cuda.synchronize()
+                        dev.launch_view(view, mrd, window=window, d_counts=dc.data_ptr() if want_c else 0,
+                                        d_bytes=db.data_ptr() if want_b else 0, stream=torch.cuda.current_stream().cuda_stream,
+                                        kernel="group", precision=precision)
+                        torch.cuda.synchronize()
+                        tag = (view, window, mrd, precision, cyc, want_c, want_b)
+                        if want_c:
+                            got = dc.cpu().numpy().reshape(nrows, ncols)
+                            assert np.array_equal(got, oc), (tag, int((got != oc).sum()))
+                        if want_b:
+                            assert np.array_equal(db.cpu().numpy().reshape(nrows, ncols), ob), tag
 
 
 def test_quantiser_every_count_on_device(gpu, oracle):
