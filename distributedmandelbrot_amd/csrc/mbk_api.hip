@@ -281,9 +281,18 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     StreamScratch *order_sc = nullptr;
     // order 3 = "units" (mbk_units.h): the light blocks of eight neighbouring block columns are ONE workgroup.  Where the
     // units kernel cannot serve a launch (outputs, widths, step counts it has no form for) the launch takes order 2.
-    const bool units = order_mode == 3 && wpw == 1u && kernel == MBK_KERNEL_GROUP && !safe && a.smooth == nullptr &&
-                       (a.counts || a.bytes) && !(a.bytes && a.quant_wide) && a.blocks_x % 8u == 0u && a.blocks_x <= 2048u &&
-                       a.fast_bx_end > 0u && a.fast_by_end > 0u && (f32 || ctx->opt[MBK_OPT_GROUP_STEPS] == 16u);
+    bool units = order_mode == 3 && wpw == 1u && kernel == MBK_KERNEL_GROUP && !safe && a.smooth == nullptr &&
+                 (a.counts || a.bytes) && !(a.bytes && a.quant_wide) && a.blocks_x % 8u == 0u && a.blocks_x <= 2048u &&
+                 a.fast_bx_end > 0u && a.fast_by_end > 0u && (f32 || ctx->opt[MBK_OPT_GROUP_STEPS] == 16u) &&
+                 grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps && by <= 0xffffu;
+    // ... and only where there is light area to batch: the share of the host's 16 x 16 probe pixels of the window that is gone
+    // after 4 steps (a deterministic function of the window).  Measured (profiles/r04/units_ab.txt): cfg2 (0.64 light) strict
+    // -0.3 % / cycle test +4.7 %, DataChunk (1,0,0) (0.8) +2.1 % / +9.7 %, cfg3 (none) -0.7 % / 0.
+    double unit_share = 0.0;
+    if (units) {
+        unit_share = window_heavy_share(a);
+        units = (1.0 - unit_share) * 65536.0 >= (double)ctx->opt[MBK_OPT_UNITS_MIN_LIGHT];
+    }
     if (order_mode >= 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps && a.blocks_x <= 0xffffu && by <= 0xffffu) {
         // (a list entry packs block row and workgroup column into 16 bits each; wider windows go in image order)
         // heavy-first dispatch order (see classify_blocks_kernel); small launches skip it: one kernel in image
@@ -348,7 +357,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         // Grid: the host cannot know how many units the probe makes of this window, so it estimates them from its own
         // 16 x 16 probe (share of the pixels still inside after 4 steps ~ the H and M blocks; the rest, eight to a unit)
         // and the kernel strides: a deterministic function of the window, no hint from earlier launches.
-        const double share = window_heavy_share(a);
+        const double share = unit_share;
         const double est = (double)grid.x * (share + (1.0 - share) / 8.0);
         const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
         uint32_t g = (uint32_t)std::min<double>((double)grid.x, est * 1.15 + 2048.0);
@@ -878,10 +887,11 @@ int mbk_create(int device, mbk_ctx **out)
     if (!ctx) return fail(nullptr, MBK_ERR_NOMEM, "out of host memory");
     ctx->device = device;
     static const uint32_t kDefaults[MBK_OPT_COUNT_] = {
-        /* ORDER */ 2u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
+        /* ORDER */ 3u, /* WAVES_PER_WG */ 1u, /* GROUP_STEPS */ 16u, /* EXACT_STEPS */ 8u, /* PROBE_STEPS */ 32u,
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
-        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u};
+        /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
+        /* UNITS_MIN_LIGHT */ 32768u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1320,6 +1330,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;
+        case MBK_OPT_UNITS_MIN_LIGHT: ok = value <= 65536u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

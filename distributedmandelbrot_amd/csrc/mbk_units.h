@@ -90,8 +90,19 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
 // Workgroup j: units j, j + G, ... (G = p.unit_stride: the grid size, passed as an argument -- gridDim.x lives in the
 // dispatch packet in host memory and would be re-read on every trip).  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
 template <typename T, int kGroup, bool kCycle, bool kCounts, bool kBytes>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_units_kernel(TileArgs p, uint32_t qtab)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_units_kernel(TileArgs args, uint32_t qtab)
 {
+    // The loop keeps the launch's arguments alive across a whole block, and the escape loops need their share of the 96
+    // scalar registers that 8 waves per SIMD leave a wave.  What this kernel never uses is pinned to the value the host
+    // guarantees (launch_blocks: no smooth output, no 64-bit quantiser, non-zero steps, no fused statistics), so that the
+    // code -- and the registers -- for it disappear.
+    TileArgs p = args;
+    p.smooth = nullptr;
+    p.stats = nullptr;
+    p.quant_wide = 0u;
+    p.re.step_is_zero = p.im.step_is_zero = 0u;
+    if (!kCounts) p.counts = nullptr;
+    if (!kBytes) p.bytes = nullptr;
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t n = p.ngrid;

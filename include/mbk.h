@@ -229,7 +229,7 @@ int mbk_serialize_last(mbk_ctx *ctx, uint8_t *h_out, uint64_t cap, uint64_t *siz
  * range.  Defaults in brackets.
  */
 enum mbk_option {
-    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order. 0 image order, 1 multiplicative permutation, 2 heavy-first list
+    MBK_OPT_ORDER = 0,     /* asm/group: workgroup order ([3] since round 4). 0 image order, 1 multiplicative permutation, 2 heavy-first list
                               (probe never escaped first; optionally a middle class, MBK_OPT_PROBE_MID), 3 "units" (round 4,
                               csrc/mbk_units.h): probe never escaped / escaped at step 4..31 one workgroup per block in that
                               order, then the blocks whose probe escaped within 3 steps eight block columns to a workgroup
@@ -275,6 +275,10 @@ enum mbk_option {
                               arbiter serves its OLDEST wave first and that 2-3 waves saturate the fp64 pipe
                               (profiles/r04/valu_issue.txt): fewer resident waves shorten the drain at the end of a
                               launch but leave fewer slots to hide the latency of light blocks */
+    MBK_OPT_UNITS_MIN_LIGHT, /* order 3: the units kernel serves a launch only when at least this share (x 65536) of the host's
+                              probe pixels of the window is gone after 4 steps -- where there is little light area to batch, the
+                              plain one-block-per-workgroup kernel (order 2) is the leaner one (cfg3: -0.7 %): 0 (always) ..
+                              65536 [32768 = one half] */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

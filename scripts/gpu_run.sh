@@ -82,6 +82,16 @@ PY
       pmcrun ${W}_${K}_a "$C1" --workload $W --kernel $K --steps 20 --warmup 5; pmcrun ${W}_${K}_b "$C2" --workload $W --kernel $K --steps 20 --warmup 5
       python scripts/pmc_summary.py "$OUT/${W}_${K}_pmc_by_kernel.json" "$OUT/pmc_${W}_${K}_a" "$OUT/pmc_${W}_${K}_b" --match tile_
       rm -rf "$OUT"/pmc_*_?;;
+  pmcopt) # PMC (instruction counts, busy, occupancy) of the default kernel with and without an option: pmcopt:NAME=V[:workloads]
+      O=${ARG%%:*}; WL=${ARG#*:}; [ "$WL" = "$ARG" ] && WL="cfg2 chunk_l1 cfg3"
+      C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+      C2="SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+      for W in $WL; do case $W in cfg3) X="--steps 4 --warmup 1";; *) X="--steps 20 --warmup 5";; esac
+        for V in base opt; do [ $V = opt ] && OO="--opt $O" || OO=""
+          pmcrun ${W}_${V}_a "$C1" --workload $W $X $OO --opt cycle_detect=0; pmcrun ${W}_${V}_b "$C2" --workload $W $X $OO --opt cycle_detect=0
+          python scripts/pmc_summary.py "$OUT/${W}_${V}_pmc_by_kernel.json" "$OUT/pmc_${W}_${V}_a" "$OUT/pmc_${W}_${V}_b" --match tile_ | cut -c1-600
+        done; done
+      rm -rf "$OUT"/pmc_*_?;;
   wg4) for rep in 1 2; do
         b cfg3_wg1_$rep --workload cfg3 --kernel group --no-cpu-baseline --no-extras --steps 12 --warmup 2
         b cfg3_wg4_$rep --workload cfg3 --kernel group --no-cpu-baseline --no-extras --steps 12 --warmup 2 --opt waves_per_wg=4

@@ -408,7 +408,8 @@ OPTION_MATRIX = [
     ("scan", {"group_steps": 32, "cycle_detect": 0}),
     ("scan", {"scan_inline": 0}), ("default", {"scan_inline": 0, "cycle_detect": 0}), ("scan", {"scan_inline": 1, "scan_waves": 2, "cycle_detect": 0}),
     ("group", {"wave_limit": 4}), ("scan", {"wave_limit": 2, "scan_inline": 0}), ("default", {"wave_limit": 7, "cycle_detect": 0}),
-    ("group", {"order": 3}), ("group", {"order": 3, "cycle_detect": 0}), ("default", {"order": 3, "exact_steps": 3, "probe_steps": 8}),
+    ("group", {"order": 3, "units_min_light": 0}), ("group", {"order": 3, "cycle_detect": 0, "units_min_light": 0}),
+    ("default", {"order": 3, "exact_steps": 3, "probe_steps": 8, "units_min_light": 0}), ("group", {"order": 3, "units_min_light": 65536}),
     ("group", {"order": 2}), ("group", {"order": 3, "group_steps": 8}), ("group", {"order": 3, "waves_per_wg": 2}),
 ]
 
@@ -459,6 +460,7 @@ def test_units_order_every_output_set_and_shape(oracle):
     ]
     with MandelbrotDevice(0) as dev:
         dev.set_option("order", 3)
+        dev.set_option("units_min_light", 0)      # every window through the units kernel, also the ones it is not the default for
         for cyc in (1, 0):
             dev.set_option("cycle_detect", cyc)
             for view, window, mrd in cases:
