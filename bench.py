@@ -145,6 +145,12 @@ def parse_args(argv=None):
                     help="tiles (or bands) in flight per GPU (default 1 for own = the contract's serial steps, 2 for queue / bands)")
     ap.add_argument("--control", default="gloo", choices=["gloo", "nccl"],
                     help="backend of the barrier / timing reductions for N > 1 (no data-path collective exists)")
+    ap.add_argument("--launch-events", default="region", choices=["region", "per-launch"],
+                    help="--shard own: where the HIP events of the timed region sit.  region (default): ONE pair around the K "
+                         "launches on the launch stream -- the average launch duration is its elapsed time / K, gaps between "
+                         "launches included; median / minimum come from a separate untimed pass with a pair per launch.  "
+                         "per-launch: a pair around every launch inside the timed region (rounds 1-3): each event is a "
+                         "barrier packet in the queue, which costs the back-to-back launches ~2 %% (profiles/r04/NOTES.md)")
     ap.add_argument("--no-solo", action="store_true",
                     help="N > 1, queue / bands: skip the single-GPU pass of the same job that rank 0 runs alone after the "
                          "timed region (`single_gpu_same_job`; it takes N times as long as the timed region)")
@@ -528,10 +534,14 @@ def main():
         """own: nsteps launches round-robin over the streams.  queue / bands: pull tickets until nsteps steps are done
         (`pullers` = the ranks pulling from the cursor: it sizes the guided chunks of the bands mode)."""
         if own_mode:
+            region = events is not None and not fake and args.launch_events == "region" and nstreams == 1
+            if region:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(streams[0])
             for _ in range(nsteps):
                 i = turn[0] % nstreams
                 turn[0] += 1
-                if events is not None and not fake:
+                if events is not None and not fake and not region:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(streams[i])
                     launch_own(i)
@@ -539,6 +549,10 @@ def main():
                     events.append((e0, e1))
                 else:
                     launch_own(i)
+            if region:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(streams[0])
+                events.append((e0, e1, nsteps))
             return
         limit = nsteps * len(units)
         while True:
@@ -617,16 +631,29 @@ def main():
         iters_per_step = sum(v[0] for v in per_tile.values())
         never = sum(v[1] for v in per_tile.values())
         kernel_ms = [elapsed / args.steps * 1e3]
+        kernel_ms_region = None
     elif fake:
         iters_per_step = 10 ** 9
         kernel_ms = [elapsed / args.steps * 1e3] * args.steps
+        kernel_ms_region = None
     else:
         if bands_mode:      # work per step = the whole image, measured once (untimed) on every rank's own GPU
             launch_own(0)
             sync()
         st = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
         iters_per_step, never = st.pixel_iterations, st.never_pixels
-        kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
+        region_events = bool(events) and len(events[0]) == 3
+        if region_events:   # one pair around the K launches: the average; then an untimed pass with a pair per launch
+            kernel_ms_region = events[0][0].elapsed_time(events[0][1]) / events[0][2]
+            per_launch = []
+            saved, args.launch_events = args.launch_events, "per-launch"
+            run_steps(min(args.steps, 64), per_launch)
+            sync()
+            args.launch_events = saved
+            kernel_ms = [a.elapsed_time(b) for a, b in per_launch]
+        else:
+            kernel_ms_region = None
+            kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
 
     # N > 1, strong-scaling modes: the SAME job on ONE GPU, timed in this very run.  N = 1 defaults
     # to one tile per step (`--shard own`: the contract's headline), N > 1 to the tile queue, whose single-GPU rate is
@@ -711,6 +738,8 @@ def main():
 
     if rank == 0:
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+        if kernel_ms_region is not None:   # events around the whole timed region / K (what the roofline is priced on)
+            avg_kernel_s = kernel_ms_region / 1e3
         if not own_mode:      # per-GPU average time per step, idle time included
             avg_kernel_s = elapsed_max / args.steps
         cus, mhz = device_info["compute_units"], device_info["clock_mhz"]
@@ -788,8 +817,12 @@ def main():
                 "frac": achieved_tflops / peak_tflops,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                "basis": "HIP events around each launch on its stream" if own_mode
+                "basis": ("one pair of HIP events on the launch stream around the K launches of the timed region, elapsed / K "
+                          "(gaps between launches included); median / min / kernel_ms_avg_per_launch_pass: an untimed pass of "
+                          f"{len(kernel_ms)} launches with a pair of events per launch" if kernel_ms_region is not None else
+                          "HIP events around each launch on its stream") if own_mode
                          else "whole-job wall time per step per GPU (idle time included)",
+                "kernel_ms_avg_per_launch_pass": sum(kernel_ms) / len(kernel_ms) if kernel_ms_region is not None else None,
                 "kernel_ms_avg": avg_kernel_s * 1e3,
                 "kernel_ms_median": sorted(kernel_ms)[len(kernel_ms) // 2] if own_mode else avg_kernel_s * 1e3,
                 "kernel_ms_min": min(kernel_ms),

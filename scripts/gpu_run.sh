@@ -92,6 +92,10 @@ PY
           python scripts/pmc_summary.py "$OUT/${W}_${V}_pmc_by_kernel.json" "$OUT/pmc_${W}_${V}_a" "$OUT/pmc_${W}_${V}_b" --match tile_ | cut -c1-600
         done; done
       rm -rf "$OUT"/pmc_*_?;;
+  events) for rep in 1 2; do for W in cfg2 chunk_l1; do
+        b ${W}_region_$rep --workload $W --no-cpu-baseline --no-extras --launch-events region
+        b ${W}_perlaunch_$rep --workload $W --no-cpu-baseline --no-extras --launch-events per-launch
+      done; done;;
   wg4) for rep in 1 2; do
         b cfg3_wg1_$rep --workload cfg3 --kernel group --no-cpu-baseline --no-extras --steps 12 --warmup 2
         b cfg3_wg4_$rep --workload cfg3 --kernel group --no-cpu-baseline --no-extras --steps 12 --warmup 2 --opt waves_per_wg=4
