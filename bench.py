@@ -107,7 +107,7 @@ DEFAULT_STEPS = {"cfg1": (400, 50), "cfg2": (400, 50), "chunk_l1": (400, 50), "i
                  "cfg3": (20, 3), "cfg4": (3, 1), "cfg5": (40, 5)}
 # CPU baseline sample: every `stride`-th 8-row band, sized for ~10-30 CPU-seconds on >= 64 host threads
 CPU_SAMPLE_STRIDE = {"cfg4": 256}
-PMC_SUMMARIES = [("r03", "cfg2_default_pmc_summary.json"), ("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
+PMC_SUMMARIES = [("r04", "cfg2_default_pmc_summary.json"), ("r03", "cfg2_default_pmc_summary.json"), ("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
 
 
 def parse_args(argv=None):

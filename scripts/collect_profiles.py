@@ -27,18 +27,17 @@ for extra in ("rocminfo.txt", "nproc.txt", "valu_rates.log", "level16.log", "wor
 by = os.path.join(src, "cfg2_default_pmc_by_kernel.json")
 if os.path.exists(by):
     d = json.load(open(by))
-    # the strict kernel (cycle test off) is the one the headline is measured on; the cycle-test instantiation
-    # (last template argument true) is in the by-kernel file
-    dom = max((k for k in d if k.startswith("tile_asm_kernel") and not k.rstrip(">").endswith("true")),
-              key=lambda k: d[k].get("SQ_INSTS_VALU", {}).get("mean", 0), default=None)
+    # the strict kernel (cycle test off) is the one the headline is measured on: of the tile kernels of the run (both legs
+    # are in it) the one with the most vector instructions per launch -- the cycle test only ever removes instructions
+    dom = max((k for k in d if k.startswith("tile_")), key=lambda k: d[k].get("SQ_INSTS_VALU", {}).get("mean", 0), default=None)
     if dom:
         out = {"kernel": dom}
         # the sources the counters were collected on: bench.py quotes `traffic` only while they match the tree
         sha = os.path.join(src, "source_sha256.txt")
         if os.path.exists(sha):
             out["source_sha256"] = open(sha).read().split()[-1]
-        out["note"] = ("vgpr_as_reported is rocprofv3's VGPR_Count = (granulated count + 1) x 4, i.e. half of the 48 registers "
-                       "allocated for the 42 the ISA uses (gfx950 allocates in granules of 8)")
+        out["note"] = ("vgpr_as_reported is rocprofv3's VGPR_Count = (granulated count + 1) x 4, i.e. half of the registers "
+                       "allocated (gfx950 allocates in granules of 8)")
         out.update(d[dom])
         json.dump(out, open(os.path.join(dst, "cfg2_default_pmc_summary.json"), "w"), indent=1)
 print(sorted(os.listdir(dst)))
