@@ -266,7 +266,11 @@ static double window_heavy_share(const TileArgs &a);
 
 // Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
 // (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
-static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, bool f32, hipStream_t stream)
+// fuse / counts_unwanted / fused: as for launch_scan_t -- partial-result slots (already zeroed on `stream`) to which a kernel
+// that can do so adds the tile's pixel-iterations and never-escaped count itself (the units kernel, when the int32 counts in
+// `a` exist for the statistics only: it then writes none); *fused says whether it did.
+static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, bool f32, hipStream_t stream,
+                         ReduceSlot *fuse = nullptr, bool counts_unwanted = false, bool *fused = nullptr)
 {
     const uint32_t wpw = ctx->opt[MBK_OPT_WAVES_PER_WG];  // 8x8-pixel blocks (= waves) per workgroup
     a.blocks_x = (a.ncols + 8u * wpw - 1u) / (8u * wpw);
@@ -367,9 +371,17 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         if (a.bytes && a.mrd > 0)
             for (uint32_t c = 1; c <= 4u; ++c)
                 qtab |= (uint32_t)(((uint64_t)c * 256u + (uint32_t)a.mrd - 1u) / (uint32_t)a.mrd & 0xffu) << (8u * (c - 1u));
+        const bool stats = fuse != nullptr && counts_unwanted && a.bytes != nullptr;
+        if (stats) {
+            a.stats = fuse;
+            a.counts = nullptr;
+            if (fused) *fused = true;
+        }
 #define MBK_LAUNCH_UNITS(T, G, CYC)                                                                                         \
     do {                                                                                                                   \
-        if (a.counts && a.bytes)                                                                                           \
+        if (stats)                                                                                                         \
+            hipLaunchKernelGGL((mbk::tile_units_kernel<T, G, CYC, false, true, true>), dim3(g), dim3(64), lds, stream, a, qtab); \
+        else if (a.counts && a.bytes)                                                                                      \
             hipLaunchKernelGGL((mbk::tile_units_kernel<T, G, CYC, true, true>), dim3(g), dim3(64), lds, stream, a, qtab);   \
         else if (a.bytes)                                                                                                  \
             hipLaunchKernelGGL((mbk::tile_units_kernel<T, G, CYC, false, true>), dim3(g), dim3(64), lds, stream, a, qtab);  \
@@ -748,13 +760,13 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
             const double share = window_heavy_share(a);
             if (kernel == MBK_KERNEL_DEFAULT &&
                 (share * 65536.0 > (double)ctx->opt[MBK_OPT_HEAVY_SHARE] || ctx->opt[MBK_OPT_HEAVY_SHARE] == 0u))
-                return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+                return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream, fuse, counts_unwanted, fused);
             return f32 ? launch_scan_t<float>(ctx, a, safe, stream, share, fuse, counts_unwanted, fused)
                        : launch_scan_t<double>(ctx, a, safe, stream, share, fuse, counts_unwanted, fused);
         }
         case MBK_KERNEL_GROUP:
         case MBK_KERNEL_ASM:
-            return launch_blocks(ctx, a, kernel, safe, f32, stream);
+            return launch_blocks(ctx, a, kernel, safe, f32, stream, fuse, counts_unwanted, fused);
         case MBK_KERNEL_REFILL:
             return launch_refill(ctx, a, safe, stream);
         case MBK_KERNEL_SIMPLE: {

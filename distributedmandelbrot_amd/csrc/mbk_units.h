@@ -89,9 +89,17 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
 
 // Workgroup j: units j, j + G, ... (G = p.unit_stride: the grid size, passed as an argument -- gridDim.x lives in the
 // dispatch packet in host memory and would be re-read on every trip).  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
-template <typename T, int kGroup, bool kCycle, bool kCounts, bool kBytes>
+// kStats (bytes-only instantiation): the kernel adds the tile's pixel-iterations and never-escaped count to args.stats itself --
+// per lane in registers over the wave's units, one reduction and two atomics per wave -- so that a DataChunk whose caller
+// wants bytes only writes no int32 counts and the statistics pass reads the 16 MiB of bytes only (what the finish-in-place
+// light pass of kernel "scan" does for all-exterior tiles, here for the tiles that hold part of the set).
+template <typename T, int kGroup, bool kCycle, bool kCounts, bool kBytes, bool kStats = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_units_kernel(TileArgs args, uint32_t qtab)
 {
+    static_assert(!kStats || (!kCounts && kBytes), "fused statistics exist for the bytes-only instantiation");
+    unsigned long long heavy_iters = 0;     // pixel-iterations / never-escaped pixels of the blocks computed by block_pixel
+    uint32_t heavy_never = 0, acc = 0;      // acc: counts of the blocks the light path finished (<= 4 each)
+    const uint32_t never_cap = args.mrd > 1 ? (uint32_t)args.mrd - 1u : 0u;
     // The loop keeps the launch's arguments alive across a whole block, and the escape loops need their share of the 96
     // scalar registers that 8 waves per SIMD leave a wave.  What this kernel never uses is pinned to the value the host
     // guarantees (launch_blocks: no smooth output, no 64-bit quantiser, non-zero steps, no fused statistics), so that the
@@ -116,7 +124,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             // by itself; the address is wave-uniform: say so)
             const uint32_t e = uniform_u32(is_h ? p.order[u] : p.order[n + 3u + (u - n_h)]);
             const uint32_t by = e >> 16, bx = e & 0xffffu;
-            block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h, bx < p.fast_bx_end && by < p.fast_by_end);
+            const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h,
+                                                                   bx < p.fast_bx_end && by < p.fast_by_end);
+            if (kStats && c >= 0) {
+                heavy_iters += c > 0 ? (uint32_t)c : never_cap;
+                heavy_never += c == 0 ? 1u : 0u;
+            }
         } else {
             const uint32_t v = uniform_u32(p.order[n - 1u - (u - n_h - n_m)]);
             const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
@@ -129,11 +142,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const uint32_t col = p.col0 + bx0 * 8u + lx, off = (ly * p.out_pitch + lx) * oscale;
             uint32_t k = 0;
             int32_t cnt;
-            while (escape_light_row<kCounts, kBytes>(ci, b0, col, p.re.step, p.re.start, cnt, cb, bb, off, 8u * oscale, qtab, mask, k) != 0u) {
+            while (escape_light_row<kCounts, kBytes, kStats>(ci, b0, col, p.re.step, p.re.start, cnt, cb, bb, off, 8u * oscale, qtab, mask, k, &acc) != 0u) {
                 // block k of the unit outlives the light path (the probe saw only its centre pixel): the whole block, exactly
-                block_pixel<T, true, kGroup, kCycle>(p, (bx0 + k) * 8u, by * 8u, lx, ly, false, true);
+                const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, (bx0 + k) * 8u, by * 8u, lx, ly, false, true);
+                if (kStats && c >= 0) {
+                    heavy_iters += c > 0 ? (uint32_t)c : never_cap;
+                    heavy_never += c == 0 ? 1u : 0u;
+                }
                 if (++k >= 8u) break;
             }
+        }
+    }
+    if (kStats) {
+        // (acc cannot wrap: <= 4 per block, and a wave handles far fewer than 2^29 blocks)
+        const unsigned long long iters = wave_sum_u64(heavy_iters + acc), never = wave_sum_u64((unsigned long long)heavy_never);
+        ReduceOut *out = &args.stats[blockIdx.x % kReduceSlots].r;
+        if (lane == 0) {
+            if (iters) atomicAdd(&out->pixel_iterations, iters);
+            if (never) atomicAdd(&out->never_pixels, never);
         }
     }
 }

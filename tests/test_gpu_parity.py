@@ -466,8 +466,14 @@ def test_units_order_every_output_set_and_shape(oracle):
             for view, window, mrd in cases:
                 col0, row0, ncols, nrows = window if window else (0, 0, view.width, view.height)
                 for precision in ("f64", "f32"):
-                    oc, ob, _ = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd,
-                                            window=window, precision=precision)
+                    oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd,
+                                                window=window, precision=precision)
+                    # the host API with bytes only (what a DataChunk asks for): the units kernel adds up the statistics itself
+                    # and writes no int32 counts
+                    _, hb, st = dev.compute_view(view, mrd, window=window, want_counts=False, kernel="group", precision=precision)
+                    assert np.array_equal(hb, ob), (view, window, mrd, precision, cyc)
+                    assert st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum()), (view, window, mrd, precision, cyc)
+                    assert st.all_bytes_zero == bool((ob == 0).all()) and st.all_bytes_one == bool((ob == 1).all())
                     for want_c, want_b in ((True, False), (False, True), (True, True)):
                         dc = torch.full((nrows * ncols,), -9, dtype=torch.int32, device="cuda:0") if want_c else None
                         db = torch.full((nrows * ncols,), 77, dtype=torch.uint8, device="cuda:0") if want_b else None
