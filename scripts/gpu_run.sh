@@ -92,6 +92,12 @@ PY
           python scripts/pmc_summary.py "$OUT/${W}_${V}_pmc_by_kernel.json" "$OUT/pmc_${W}_${V}_a" "$OUT/pmc_${W}_${V}_b" --match tile_ | cut -c1-600
         done; done
       rm -rf "$OUT"/pmc_*_?;;
+  unitstrace) hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/units_trace profiles/microbench/units_trace.hip 2> "$OUT/build_units_trace.log"
+      for W in ${ARG:-cfg2 chunk_l1}; do
+        timeout 300 /tmp/units_trace $W "$OUT/units_trace_$W.bin" > "$OUT/units_trace_$W.txt" 2>&1
+        timeout 600 python scripts/analyze_units_trace.py "$OUT/units_trace_$W.bin" >> "$OUT/units_trace_$W.txt" 2>&1
+        cat "$OUT/units_trace_$W.txt"; rm -f "$OUT/units_trace_$W.bin"
+      done;;
   events) for rep in 1 2; do for W in cfg2 chunk_l1; do
         b ${W}_region_$rep --workload $W --no-cpu-baseline --no-extras --launch-events region
         b ${W}_perlaunch_$rep --workload $W --no-cpu-baseline --no-extras --launch-events per-launch
