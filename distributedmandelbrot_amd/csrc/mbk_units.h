@@ -34,15 +34,21 @@
 namespace mbk {
 
 // Layout of the list (same buffer as classify_blocks_kernel's): order[0 .. n) H entries from the front and V units from
-// the back, order[n .. n+3) the counters (H, V units, M), order[n+3 .. 2n+3) the M entries.  H / M entry: (block row << 16)
+// the back, order[n .. n+3) the counters (H, V units, M), order[n+3 .. 2n+3) the M entries, order[2n+3 .. 2n+3+128) the
+// pool cursors.  H / M entry: (block row << 16)
 // | block column.  V unit: (block row << 16) | (first block column / 8) << 8 | mask of the V blocks among its 8 columns.
 // Needs blocks_x % 8 == 0 (a unit never wraps a row), blocks_x <= 2048, block rows < 65536 (the host checks).
+// The pool of the tile kernel (below): 8 ticket cursors, one per XCD, each on its own 64-byte line.
+constexpr uint32_t kUnitCursorWords = 8u * 16u;
+constexpr uint32_t kUnitsPerTicket = 4u;
+
 __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
                                                               uint32_t *order, uint32_t *counters)
 {
     __shared__ uint32_t s_cnt[3][16], s_base[3];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (r < kUnitCursorWords) order[2u * nregions + 3u + r] = 0u;   // the tile kernel's pool cursors (behind the M list)
     const bool valid = r < nregions;
     uint32_t cls = 3u;     // 0 H, 1 V, 2 M, 3 nothing
     uint32_t by = 0, bx = 0;
@@ -87,8 +93,17 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
     if (emit[2]) order[nregions + 3u + s_base[2] + s_cnt[2][wave] + (uint32_t)__popcll(m[2] & below)] = (by << 16) | bx;
 }
 
-// Workgroup j: units j, j + G, ... (G = p.unit_stride: the grid size, passed as an argument -- gridDim.x lives in the
-// dispatch packet in host memory and would be re-read on every trip).  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
+// Which workgroup computes which unit.  The hardware deals workgroup ids to the 8 XCDs in turn and every XCD works through
+// its ids on its own -- and the XCDs of one chip do not run at one speed: profiles/r04/units_trace_*.txt (a time stamp per
+// workgroup) shows the same ids finishing 5-10 % apart, XCD by XCD, the same XCDs slow on every tile, so that with units
+// dealt by id the fast XCDs sit idle for the last 6 % of a launch -- the "drain" rounds 1-3 could not explain.  So the units
+// are split: the first S (all of H, half of M) are STATIC, unit j to workgroup j; the rest (the other half of M, then all V
+// units) is a POOL that the workgroups with ids >= S drain through tickets of 4 units -- 8 cursors, one per XCD, ticket
+// 8 k + x from cursor x, each on its own cache line; a workgroup whose XCD's cursor has run out takes from the next XCD's --
+// so an XCD that is through with its static share early simply takes more of the pool.  ~9 000 atomics per cfg2 launch.
+// If the host's grid estimate G leaves no workgroup for the pool (G <= S) every workgroup strides over all units instead
+// (j, j + G, ...), as before.  G = p.unit_stride, passed as an argument: gridDim.x lives in the dispatch packet in host
+// memory and would be re-read on every trip.  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
 // kStats (bytes-only instantiation): the kernel adds the tile's pixel-iterations and never-escaped count to args.stats itself --
 // per lane in registers over the wave's units, one reduction and two atomics per wave -- so that a DataChunk whose caller
 // wants bytes only writes no int32 counts and the statistics pass reads the 16 MiB of bytes only (what the finish-in-place
@@ -117,7 +132,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t n_h = uniform_u32(p.order[n]), n_v = uniform_u32(p.order[n + 1u]), n_m = uniform_u32(p.order[n + 2u]);
     const uint32_t total = n_h + n_m + n_v;
     const uint32_t oscale = kCounts ? 4u : 1u;
-    for (uint32_t u = blockIdx.x; u < total; u += p.unit_stride) {
+    const uint32_t n_static = n_h + n_m - (n_m >> 1);               // S: all of H, the first half of M
+    const uint32_t n_tickets = (total - n_static + kUnitsPerTicket - 1u) / kUnitsPerTicket;
+    const bool pooled = p.unit_pool != 0u && p.unit_stride > n_static;   // some workgroup exists that drains the pool
+    const bool drains = pooled && blockIdx.x >= n_static;
+    unsigned int *cursors = const_cast<unsigned int *>(p.order) + 2u * n + 3u;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   // HW_REG_XCC_ID
+    uint32_t probe = 0u, left = 0u, u = blockIdx.x;
+    // the next ticket of this XCD's cursor, or of the next XCD's that has any left: its first unit, or `total` when all are gone
+    auto take = [&]() -> uint32_t {
+        for (; probe < 8u; ++probe) {
+            const uint32_t x = (xcc + probe) & 7u;
+            uint32_t k = 0u;
+            if (lane == 0u) k = atomicAdd(cursors + 16u * x, 1u);
+            const uint32_t t = 8u * uniform_u32(k) + x;
+            if (t < n_tickets) return n_static + kUnitsPerTicket * t;
+        }
+        return total;
+    };
+    if (drains) {
+        u = take();
+        left = kUnitsPerTicket;
+    }
+    while (u < total) {
         if (u < n_h + n_m) {
             const bool is_h = u < n_h;
             // (loads inside the loop follow this wave's own stores, so the compiler will not keep them on the scalar unit
@@ -151,6 +188,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 }
                 if (++k >= 8u) break;
             }
+        }
+        // the next unit of this workgroup
+        if (!pooled) {
+            u += p.unit_stride;
+        } else if (!drains) {
+            break;                       // a static workgroup: its one unit
+        } else if (--left != 0u && u + 1u < total) {
+            ++u;
+        } else {
+            u = take();
+            left = kUnitsPerTicket;
         }
     }
     if (kStats) {
