@@ -135,20 +135,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t n_static = n_h + n_m - (n_m >> 1);               // S: all of H, the first half of M
     const uint32_t n_tickets = (total - n_static + kUnitsPerTicket - 1u) / kUnitsPerTicket;
     const bool pooled = p.unit_pool != 0u && p.unit_stride > n_static;   // some workgroup exists that drains the pool
-    const bool drains = pooled && blockIdx.x >= n_static;
+    // the workgroups right behind the static ones drain the pool: one per two tickets is plenty (each loops until the pool is
+    // empty); the ids behind them have nothing to do and leave without touching a cursor
+    const uint32_t n_drainers = n_tickets / 2u + 64u;
+    const bool drains = pooled && blockIdx.x >= n_static && blockIdx.x - n_static < n_drainers;
+    if (pooled && !drains && blockIdx.x >= n_static) return;
     unsigned int *cursors = const_cast<unsigned int *>(p.order) + 2u * n + 3u;
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   // HW_REG_XCC_ID
-    uint32_t probe = 0u, left = 0u, u = blockIdx.x;
-    // the next ticket of this XCD's cursor, or of the next XCD's that has any left: its first unit, or `total` when all are gone
+    uint32_t left = 0u, u = blockIdx.x;
+    // The next ticket: ONE load shows all eight cursors (lane x reads cursor x), the first one at or after this XCD's own that
+    // has tickets left gets the atomic.  A ticket is 8 k + x for the k-th taker of cursor x, so a taker that overshoots has
+    // found the cursor exhausted for good and looks again; when no cursor has any left, every ticket has been taken.
     auto take = [&]() -> uint32_t {
-        for (; probe < 8u; ++probe) {
-            const uint32_t x = (xcc + probe) & 7u;
+        for (;;) {
+            uint32_t cur = 0u;
+            if (lane < 8u) cur = __hip_atomic_load(cursors + 16u * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t avail = (uint32_t)(__ballot(lane < 8u && (unsigned long long)cur * 8u + lane < n_tickets) & 0xffull);
+            if (avail == 0u) return total;
+            const uint32_t rot = ((avail >> xcc) | (avail << (8u - xcc))) & 0xffu;
+            const uint32_t x = (xcc + (uint32_t)__builtin_ctz(rot)) & 7u;
             uint32_t k = 0u;
             if (lane == 0u) k = atomicAdd(cursors + 16u * x, 1u);
             const uint32_t t = 8u * uniform_u32(k) + x;
             if (t < n_tickets) return n_static + kUnitsPerTicket * t;
         }
-        return total;
     };
     if (drains) {
         u = take();
