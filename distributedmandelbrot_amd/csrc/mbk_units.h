@@ -133,11 +133,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t total = n_h + n_m + n_v;
     const uint32_t oscale = kCounts ? 4u : 1u;
     const uint32_t n_static = n_h + n_m - (n_m >> 1);               // S: all of H, the first half of M
-    const uint32_t n_tickets = (total - n_static + kUnitsPerTicket - 1u) / kUnitsPerTicket;
+    // tickets: the pooled M blocks one by one (a boundary block can run all mrd - 1 steps: four of them behind one another in
+    // one wave were the launch's tail), then the V units four at a time
+    const uint32_t n_pool_m = n_h + n_m - n_static;
+    const uint32_t n_tickets = n_pool_m + (n_v + kUnitsPerTicket - 1u) / kUnitsPerTicket;
     const bool pooled = p.unit_pool != 0u && p.unit_stride > n_static;   // some workgroup exists that drains the pool
-    // the workgroups right behind the static ones drain the pool: one per two tickets is plenty (each loops until the pool is
-    // empty); the ids behind them have nothing to do and leave without touching a cursor
-    const uint32_t n_drainers = n_tickets / 2u + 64u;
+    // the workgroups right behind the static ones drain the pool, each looping until it is empty; the ids behind them have
+    // nothing to do and leave without touching a cursor
+    const uint32_t n_drainers = n_tickets < 24576u ? n_tickets + 64u : 24576u;   // (three times what the chip holds)
     const bool drains = pooled && blockIdx.x >= n_static && blockIdx.x - n_static < n_drainers;
     if (pooled && !drains && blockIdx.x >= n_static) return;
     unsigned int *cursors = const_cast<unsigned int *>(p.order) + 2u * n + 3u;
@@ -157,13 +160,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             uint32_t k = 0u;
             if (lane == 0u) k = atomicAdd(cursors + 16u * x, 1u);
             const uint32_t t = 8u * uniform_u32(k) + x;
-            if (t < n_tickets) return n_static + kUnitsPerTicket * t;
+            if (t < n_pool_m) {
+                left = 1u;
+                return n_static + t;
+            }
+            if (t < n_tickets) {
+                left = kUnitsPerTicket;
+                return n_static + n_pool_m + kUnitsPerTicket * (t - n_pool_m);
+            }
         }
     };
-    if (drains) {
-        u = take();
-        left = kUnitsPerTicket;
-    }
+    if (drains) u = take();
     while (u < total) {
         if (u < n_h + n_m) {
             const bool is_h = u < n_h;
@@ -208,7 +215,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             ++u;
         } else {
             u = take();
-            left = kUnitsPerTicket;
         }
     }
     if (kStats) {
