@@ -38,8 +38,10 @@ namespace mbk {
 // pool cursors.  H / M entry: (block row << 16)
 // | block column.  V unit: (block row << 16) | (first block column / 8) << 8 | mask of the V blocks among its 8 columns.
 // Needs blocks_x % 8 == 0 (a unit never wraps a row), blocks_x <= 2048, block rows < 65536 (the host checks).
-// The pool of the tile kernel (below): 8 ticket cursors, one per XCD, each on its own 64-byte line.
-constexpr uint32_t kUnitCursorWords = 8u * 16u;
+// The pool of the tile kernel (below): 128 ticket cursors, 16 per XCD, each on its own 64-byte line (a device-scope atomic on
+// ONE address costs ~0.2 us under contention: with 8 cursors 27 000 tickets took 650 us).
+constexpr uint32_t kUnitCursors = 128u;
+constexpr uint32_t kUnitCursorWords = kUnitCursors * 16u;
 constexpr uint32_t kUnitsPerTicket = 4u;
 
 __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
     __shared__ uint32_t s_cnt[3][16], s_base[3];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (r < kUnitCursorWords) order[2u * nregions + 3u + r] = 0u;   // the tile kernel's pool cursors (behind the M list)
+    for (uint32_t w = r; w < kUnitCursorWords; w += gridDim.x * blockDim.x) order[2u * nregions + 3u + w] = 0u;   // the tile kernel's pool cursors (behind the M list)
     const bool valid = r < nregions;
     uint32_t cls = 3u;     // 0 H, 1 V, 2 M, 3 nothing
     uint32_t by = 0, bx = 0;
@@ -150,16 +152,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // has tickets left gets the atomic.  A ticket is 8 k + x for the k-th taker of cursor x, so a taker that overshoots has
     // found the cursor exhausted for good and looks again; when no cursor has any left, every ticket has been taken.
     auto take = [&]() -> uint32_t {
+        // cursor c hands out tickets 128 k + c; this workgroup starts at one of its XCD's 16 cursors and moves on (cyclically)
+        // to the next cursor that has tickets left: two loads show all 128 (lane l reads cursors l and l + 64)
+        const uint32_t home = (xcc << 4) | (blockIdx.x & 15u);
         for (;;) {
-            uint32_t cur = 0u;
-            if (lane < 8u) cur = __hip_atomic_load(cursors + 16u * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t avail = (uint32_t)(__ballot(lane < 8u && (unsigned long long)cur * 8u + lane < n_tickets) & 0xffull);
-            if (avail == 0u) return total;
-            const uint32_t rot = ((avail >> xcc) | (avail << (8u - xcc))) & 0xffu;
-            const uint32_t x = (xcc + (uint32_t)__builtin_ctz(rot)) & 7u;
+            const uint32_t c0 = __hip_atomic_load(cursors + 16u * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t c1 = __hip_atomic_load(cursors + 16u * (lane + 64u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long a0 = __ballot((unsigned long long)c0 * kUnitCursors + lane < n_tickets);
+            const unsigned long long a1 = __ballot((unsigned long long)c1 * kUnitCursors + lane + 64u < n_tickets);
+            if ((a0 | a1) == 0ull) return total;
+            // first available cursor at or after `home`, cyclically over 128
+            uint32_t x = kUnitCursors;
+            for (uint32_t step = 0; step < 2u && x == kUnitCursors; ++step) {
+                const uint32_t from = step == 0u ? home : 0u;
+                const unsigned long long m0 = from < 64u ? a0 & (~0ull << from) : 0ull;
+                const unsigned long long m1 = from < 64u ? a1 : a1 & (~0ull << (from - 64u));
+                if (m0) x = (uint32_t)__builtin_ctzll(m0);
+                else if (m1) x = 64u + (uint32_t)__builtin_ctzll(m1);
+            }
             uint32_t k = 0u;
             if (lane == 0u) k = atomicAdd(cursors + 16u * x, 1u);
-            const uint32_t t = 8u * uniform_u32(k) + x;
+            const uint32_t t = kUnitCursors * uniform_u32(k) + x;
             if (t < n_pool_m) {
                 left = 1u;
                 return n_static + t;
