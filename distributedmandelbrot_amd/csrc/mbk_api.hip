@@ -322,9 +322,9 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                 sc->done_valid[k] = false;
             }
             sc->order_cap = 0;
-            // list | 3 counters | middle-class list (classify_blocks_kernel) | the units kernel's pool cursors
+            // list | 3 counters | middle-class list (classify_blocks_kernel)
             for (int k = 0; k < 2; ++k)
-                MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], (2u * (size_t)grid.x + 3u + mbk::kUnitCursorWords) * sizeof(uint32_t)));
+                MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], (2u * (size_t)grid.x + 3u) * sizeof(uint32_t)));
             sc->order_cap = grid.x;
         }
         // Pre-pass of THIS launch on the aux stream: it depends on the window only, not on anything the caller's
@@ -367,7 +367,6 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         uint32_t g = (uint32_t)std::min<double>((double)grid.x, est * 1.15 + 2048.0);
         g = std::max(g, std::min(grid.x, cus * 64u));
         a.unit_stride = g;
-        a.unit_pool = ctx->opt[MBK_OPT_UNITS_POOL];
         uint32_t qtab = 0u;   // quantised bytes of counts 1..4, packed (the light path's table)
         if (a.bytes && a.mrd > 0)
             for (uint32_t c = 1; c <= 4u; ++c)
@@ -904,7 +903,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* UNITS_POOL */ 1u};
+        /* UNITS_MIN_LIGHT */ 32768u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1344,7 +1343,6 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;
         case MBK_OPT_UNITS_MIN_LIGHT: ok = value <= 65536u; break;
-        case MBK_OPT_UNITS_POOL: ok = value <= 1u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

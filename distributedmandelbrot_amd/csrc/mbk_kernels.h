@@ -59,7 +59,6 @@ struct TileArgs {
     uint32_t ngrid;        // with `order`: the grid size (= list length); the counters sit at order[ngrid .. ngrid + 3)
     uint32_t order_mid;    // with `order`: 1 = a middle class was built (MBK_OPT_PROBE_MID <= probe depth)
     uint32_t unit_stride;  // kernel "units" (mbk_units.h): the grid size G; workgroup j takes units j, j + G, ...
-    uint32_t unit_pool;    // ... 1: the last units are a pool drained through per-XCD tickets (MBK_OPT_UNITS_POOL)
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
     double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value

@@ -34,23 +34,15 @@
 namespace mbk {
 
 // Layout of the list (same buffer as classify_blocks_kernel's): order[0 .. n) H entries from the front and V units from
-// the back, order[n .. n+3) the counters (H, V units, M), order[n+3 .. 2n+3) the M entries, order[2n+3 .. 2n+3+128) the
-// pool cursors.  H / M entry: (block row << 16)
+// the back, order[n .. n+3) the counters (H, V units, M), order[n+3 .. 2n+3) the M entries.  H / M entry: (block row << 16)
 // | block column.  V unit: (block row << 16) | (first block column / 8) << 8 | mask of the V blocks among its 8 columns.
 // Needs blocks_x % 8 == 0 (a unit never wraps a row), blocks_x <= 2048, block rows < 65536 (the host checks).
-// The pool of the tile kernel (below): 128 ticket cursors, 16 per XCD, each on its own 64-byte line (a device-scope atomic on
-// ONE address costs ~0.2 us under contention: with 8 cursors 27 000 tickets took 650 us).
-constexpr uint32_t kUnitCursors = 128u;
-constexpr uint32_t kUnitCursorWords = kUnitCursors * 16u;
-constexpr uint32_t kUnitsPerTicket = 4u;
-
 __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
                                                               uint32_t *order, uint32_t *counters)
 {
     __shared__ uint32_t s_cnt[3][16], s_base[3];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t w = r; w < kUnitCursorWords; w += gridDim.x * blockDim.x) order[2u * nregions + 3u + w] = 0u;   // the tile kernel's pool cursors (behind the M list)
     const bool valid = r < nregions;
     uint32_t cls = 3u;     // 0 H, 1 V, 2 M, 3 nothing
     uint32_t by = 0, bx = 0;
@@ -95,17 +87,8 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
     if (emit[2]) order[nregions + 3u + s_base[2] + s_cnt[2][wave] + (uint32_t)__popcll(m[2] & below)] = (by << 16) | bx;
 }
 
-// Which workgroup computes which unit.  The hardware deals workgroup ids to the 8 XCDs in turn and every XCD works through
-// its ids on its own -- and the XCDs of one chip do not run at one speed: profiles/r04/units_trace_*.txt (a time stamp per
-// workgroup) shows the same ids finishing 5-10 % apart, XCD by XCD, the same XCDs slow on every tile, so that with units
-// dealt by id the fast XCDs sit idle for the last 6 % of a launch -- the "drain" rounds 1-3 could not explain.  So the units
-// are split: the first S (all of H, half of M) are STATIC, unit j to workgroup j; the rest (the other half of M, then all V
-// units) is a POOL that the workgroups with ids >= S drain through tickets of 4 units -- 8 cursors, one per XCD, ticket
-// 8 k + x from cursor x, each on its own cache line; a workgroup whose XCD's cursor has run out takes from the next XCD's --
-// so an XCD that is through with its static share early simply takes more of the pool.  ~9 000 atomics per cfg2 launch.
-// If the host's grid estimate G leaves no workgroup for the pool (G <= S) every workgroup strides over all units instead
-// (j, j + G, ...), as before.  G = p.unit_stride, passed as an argument: gridDim.x lives in the dispatch packet in host
-// memory and would be re-read on every trip.  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
+// Workgroup j: units j, j + G, ... (G = p.unit_stride: the grid size, passed as an argument -- gridDim.x lives in the
+// dispatch packet in host memory and would be re-read on every trip).  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
 // kStats (bytes-only instantiation): the kernel adds the tile's pixel-iterations and never-escaped count to args.stats itself --
 // per lane in registers over the wave's units, one reduction and two atomics per wave -- so that a DataChunk whose caller
 // wants bytes only writes no int32 counts and the statistics pass reads the 16 MiB of bytes only (what the finish-in-place
@@ -134,57 +117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t n_h = uniform_u32(p.order[n]), n_v = uniform_u32(p.order[n + 1u]), n_m = uniform_u32(p.order[n + 2u]);
     const uint32_t total = n_h + n_m + n_v;
     const uint32_t oscale = kCounts ? 4u : 1u;
-    const uint32_t n_static = n_h + n_m - (n_m >> 1);               // S: all of H, the first half of M
-    // tickets: the pooled M blocks one by one (a boundary block can run all mrd - 1 steps: four of them behind one another in
-    // one wave were the launch's tail), then the V units four at a time
-    const uint32_t n_pool_m = n_h + n_m - n_static;
-    const uint32_t n_tickets = n_pool_m + (n_v + kUnitsPerTicket - 1u) / kUnitsPerTicket;
-    const bool pooled = p.unit_pool != 0u && p.unit_stride > n_static;   // some workgroup exists that drains the pool
-    // the workgroups right behind the static ones drain the pool, each looping until it is empty; the ids behind them have
-    // nothing to do and leave without touching a cursor
-    const uint32_t n_drainers = n_tickets < 24576u ? n_tickets + 64u : 24576u;   // (three times what the chip holds)
-    const bool drains = pooled && blockIdx.x >= n_static && blockIdx.x - n_static < n_drainers;
-    if (pooled && !drains && blockIdx.x >= n_static) return;
-    unsigned int *cursors = const_cast<unsigned int *>(p.order) + 2u * n + 3u;
-    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   // HW_REG_XCC_ID
-    uint32_t left = 0u, u = blockIdx.x;
-    // The next ticket: ONE load shows all eight cursors (lane x reads cursor x), the first one at or after this XCD's own that
-    // has tickets left gets the atomic.  A ticket is 8 k + x for the k-th taker of cursor x, so a taker that overshoots has
-    // found the cursor exhausted for good and looks again; when no cursor has any left, every ticket has been taken.
-    auto take = [&]() -> uint32_t {
-        // cursor c hands out tickets 128 k + c; this workgroup starts at one of its XCD's 16 cursors and moves on (cyclically)
-        // to the next cursor that has tickets left: two loads show all 128 (lane l reads cursors l and l + 64)
-        const uint32_t home = (xcc << 4) | (blockIdx.x & 15u);
-        for (;;) {
-            const uint32_t c0 = __hip_atomic_load(cursors + 16u * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t c1 = __hip_atomic_load(cursors + 16u * (lane + 64u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long a0 = __ballot((unsigned long long)c0 * kUnitCursors + lane < n_tickets);
-            const unsigned long long a1 = __ballot((unsigned long long)c1 * kUnitCursors + lane + 64u < n_tickets);
-            if ((a0 | a1) == 0ull) return total;
-            // first available cursor at or after `home`, cyclically over 128
-            uint32_t x = kUnitCursors;
-            for (uint32_t step = 0; step < 2u && x == kUnitCursors; ++step) {
-                const uint32_t from = step == 0u ? home : 0u;
-                const unsigned long long m0 = from < 64u ? a0 & (~0ull << from) : 0ull;
-                const unsigned long long m1 = from < 64u ? a1 : a1 & (~0ull << (from - 64u));
-                if (m0) x = (uint32_t)__builtin_ctzll(m0);
-                else if (m1) x = 64u + (uint32_t)__builtin_ctzll(m1);
-            }
-            uint32_t k = 0u;
-            if (lane == 0u) k = atomicAdd(cursors + 16u * x, 1u);
-            const uint32_t t = kUnitCursors * uniform_u32(k) + x;
-            if (t < n_pool_m) {
-                left = 1u;
-                return n_static + t;
-            }
-            if (t < n_tickets) {
-                left = kUnitsPerTicket;
-                return n_static + n_pool_m + kUnitsPerTicket * (t - n_pool_m);
-            }
-        }
-    };
-    if (drains) u = take();
-    while (u < total) {
+    for (uint32_t u = blockIdx.x; u < total; u += p.unit_stride) {
         if (u < n_h + n_m) {
             const bool is_h = u < n_h;
             // (loads inside the loop follow this wave's own stores, so the compiler will not keep them on the scalar unit
@@ -218,16 +151,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 }
                 if (++k >= 8u) break;
             }
-        }
-        // the next unit of this workgroup
-        if (!pooled) {
-            u += p.unit_stride;
-        } else if (!drains) {
-            break;                       // a static workgroup: its one unit
-        } else if (--left != 0u && u + 1u < total) {
-            ++u;
-        } else {
-            u = take();
         }
     }
     if (kStats) {

@@ -279,10 +279,6 @@ enum mbk_option {
                               probe pixels of the window is gone after 4 steps -- where there is little light area to batch, the
                               plain one-block-per-workgroup kernel (order 2) is the leaner one (cfg3: -0.7 %): 0 (always) ..
                               65536 [32768 = one half] */
-    MBK_OPT_UNITS_POOL,    /* order 3: the second half of the M blocks and the V units are a pool that workgroups drain through
-                              tickets (8 cursors, one per XCD, stealing from the next when its own is empty), so that an XCD that
-                              runs faster -- the XCDs of a chip finish the same work 5-10 % apart (profiles/r04/units_trace_*.txt) --
-                              takes more of it: 0 (every unit dealt by workgroup id), [1] */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

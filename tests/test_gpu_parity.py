@@ -411,7 +411,6 @@ OPTION_MATRIX = [
     ("group", {"order": 3, "units_min_light": 0}), ("group", {"order": 3, "cycle_detect": 0, "units_min_light": 0}),
     ("default", {"order": 3, "exact_steps": 3, "probe_steps": 8, "units_min_light": 0}), ("group", {"order": 3, "units_min_light": 65536}),
     ("group", {"order": 2}), ("group", {"order": 3, "group_steps": 8}), ("group", {"order": 3, "waves_per_wg": 2}),
-    ("group", {"order": 3, "units_min_light": 0, "units_pool": 0}), ("default", {"units_pool": 0, "cycle_detect": 0}),
 ]
 
 
