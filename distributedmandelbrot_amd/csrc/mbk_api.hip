@@ -412,6 +412,8 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             if (skew == 1u) {
                 units_feedback(*order_sc);
                 std::memcpy(w, order_sc->unit_a, 8);
+            } else if (skew == 2u) {
+                std::memset(w, 32, 8);                   // the weighted code path with even weights (its own cost, for A/Bs)
             } else {
                 for (uint32_t x = 0; x < 8u; ++x) w[x] = (uint8_t)(32u - (x * (skew - 1u) * 5u) % 29u);   // 4..32, not monotonic
             }

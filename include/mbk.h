@@ -283,8 +283,8 @@ enum mbk_option {
                               chip finish equal shares 5-10 % apart, so a launch lasts as long as its slowest XCD
                               (profiles/r04/units_trace_*.txt).  [1]: behind the static units every XCD takes a_x of every 32 of its
                               ids' worth of the remaining ones, the a_x following the finish stamps that the previous launches
-                              on the stream left in pinned memory (one step per launch); 0: plain deal; 2..9: fixed test
-                              patterns of weights */
+                              on the stream left in pinned memory (one step per launch); 0: plain deal; 2: the weighted path with even
+                              weights; 3..9: fixed uneven test patterns */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
