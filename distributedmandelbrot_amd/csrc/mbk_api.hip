@@ -54,11 +54,6 @@ struct StreamScratch {
     bool cursors_dirty = false;      // a scan launch failed after its cursor sets were assigned: clear both next time
     uint32_t *h_hint = nullptr;   // pinned, written by the kernels of the last launch on this stream:
                                   // [0] longest deferred list (scan pass 2), [1] share of heavy blocks x 65536
-    // kernel "units", weighted deal (mbk_units.h): finish stamps of the previous launches (pinned, written by the kernel), the
-    // launch counter they carry, and the weights the feedback has arrived at
-    unsigned long long *h_stamps = nullptr;
-    uint32_t unit_seq = 0, unit_fb_seq = 0;
-    uint8_t unit_a[8] = {32, 32, 32, 32, 32, 32, 32, 32};
     ReduceSlot *d_red = nullptr;  // mbk_reduce_counts on this (caller) stream: its own partial results, so that a
     ReduceSlot *h_red = nullptr;  // reduction on a caller stream never shares a buffer with a tile in flight on a slot
 };
@@ -233,7 +228,6 @@ static void free_scratch(StreamScratch &sc)
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
     if (sc.h_hint) (void)hipHostFree(sc.h_hint);
-    if (sc.h_stamps) (void)hipHostFree(sc.h_stamps);
     if (sc.d_red) (void)hipFree(sc.d_red);
     if (sc.h_red) (void)hipHostFree(sc.h_red);
     sc = StreamScratch();
@@ -269,36 +263,6 @@ static int get_scratch(mbk_ctx *ctx, hipStream_t stream, StreamScratch **out)
 //                               1e-9 fp64 / 1e-3 fp32 per pixel; the host test allows 1e-6 / 2e-3).
 static void set_window_facts(TileArgs &a, bool f32);
 static double window_heavy_share(const TileArgs &a);
-
-// The feedback of the units kernel's weighted deal: the late workgroups of every XCD (= workgroup id mod 8) of a launch leave
-// (launch number, 100 MHz time) in pinned memory.  When the eight slots show one and the same launch, the XCD that finished
-// last gives up one of its 32 pool shares and the one that finished first gains one -- one step per launch, so the weights
-// settle within a few dozen launches on what the chip's XCDs actually deliver and track it afterwards (the XCDs of one
-// MI355X finish equal shares 5-10 % apart: profiles/r04/units_trace_*.txt).  A scheduling heuristic: results cannot depend on it.
-static void units_feedback(StreamScratch &sc)
-{
-    unsigned long long v[8];
-    for (int x = 0; x < 8; ++x) v[x] = ((volatile unsigned long long *)sc.h_stamps)[x];
-    const uint32_t seq = (uint32_t)(v[0] >> 32);
-    if (seq == 0u || seq == sc.unit_fb_seq) return;
-    for (int x = 1; x < 8; ++x)
-        if ((uint32_t)(v[x] >> 32) != seq) return;      // slots of different launches: wait for a complete set
-    sc.unit_fb_seq = seq;
-    int last = 0, first = 0;
-    int32_t dmax = 0, dmin = 0;
-    for (int x = 1; x < 8; ++x) {
-        const int32_t d = (int32_t)((uint32_t)v[x] - (uint32_t)v[0]);   // 10 ns ticks relative to XCD 0 (wrap-safe)
-        if (d > dmax) dmax = d, last = x;
-        if (d < dmin) dmin = d, first = x;
-    }
-    if (dmax - dmin < 300) return;                       // within 3 us of each other: leave it
-    if (sc.unit_a[last] > 4u) --sc.unit_a[last];
-    if (sc.unit_a[first] < 32u) ++sc.unit_a[first];
-    uint8_t top = 0;
-    for (int x = 0; x < 8; ++x) top = std::max(top, sc.unit_a[x]);
-    if (top < 32u)                                       // keep the scale: the fastest XCD takes every pool id
-        for (int x = 0; x < 8; ++x) sc.unit_a[x] = (uint8_t)(sc.unit_a[x] + (32u - top));
-}
 
 // Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
 // (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
@@ -400,34 +364,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         const double share = unit_share;
         const double est = (double)grid.x * (share + (1.0 - share) / 8.0);
         const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-        // the weighted deal (MBK_OPT_UNITS_SKEW: 0 plain, [1] weights from the feedback, >= 2 fixed test patterns)
-        double skew_ids = 0.0;
-        a.unit_w[0] = a.unit_w[1] = 0u;
-        if (const uint32_t skew = ctx->opt[MBK_OPT_UNITS_SKEW]) {
-            if (!order_sc->h_stamps) {
-                MBK_HIP(ctx, hipHostMalloc((void **)&order_sc->h_stamps, 8 * sizeof(unsigned long long), hipHostMallocDefault));
-                std::memset(order_sc->h_stamps, 0, 8 * sizeof(unsigned long long));
-            }
-            uint8_t w[8];
-            if (skew == 1u) {
-                units_feedback(*order_sc);
-                std::memcpy(w, order_sc->unit_a, 8);
-            } else if (skew == 2u) {
-                std::memset(w, 32, 8);                   // the weighted code path with even weights (its own cost, for A/Bs)
-            } else {
-                for (uint32_t x = 0; x < 8u; ++x) w[x] = (uint8_t)(32u - (x * (skew - 1u) * 5u) % 29u);   // 4..32, not monotonic
-            }
-            uint32_t sum = 0;
-            for (uint32_t x = 0; x < 8u; ++x) {
-                a.unit_w[x >> 2] |= (uint32_t)w[x] << (8u * (x & 3u));
-                sum += w[x];
-            }
-            a.unit_seq = ++order_sc->unit_seq;
-            if (a.unit_seq == 0u) a.unit_seq = order_sc->unit_seq = 1u;
-            a.unit_stamps = order_sc->h_stamps;
-            skew_ids = est * 0.6 * (256.0 / (double)sum - 1.0) + 1024.0;   // ids of slower XCDs that take no unit
-        }
-        uint32_t g = (uint32_t)std::min<double>((double)grid.x * 1.5, est * 1.15 + 2048.0 + skew_ids);
+        uint32_t g = (uint32_t)std::min<double>((double)grid.x, est * 1.15 + 2048.0);
         g = std::max(g, std::min(grid.x, cus * 64u));
         a.unit_stride = g;
         uint32_t qtab = 0u;   // quantised bytes of counts 1..4, packed (the light path's table)
@@ -966,7 +903,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* UNITS_SKEW */ 1u};
+        /* UNITS_MIN_LIGHT */ 32768u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1406,7 +1343,6 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;
         case MBK_OPT_UNITS_MIN_LIGHT: ok = value <= 65536u; break;
-        case MBK_OPT_UNITS_SKEW: ok = value <= 9u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

@@ -59,10 +59,6 @@ struct TileArgs {
     uint32_t ngrid;        // with `order`: the grid size (= list length); the counters sit at order[ngrid .. ngrid + 3)
     uint32_t order_mid;    // with `order`: 1 = a middle class was built (MBK_OPT_PROBE_MID <= probe depth)
     uint32_t unit_stride;  // kernel "units" (mbk_units.h): the grid size G; workgroup j takes units j, j + G, ...
-    uint32_t unit_w[2];    // ... XCD weights of the weighted deal: byte x = how many of every 32 pool ids of XCD x (= workgroup
-                           // id mod 8) take a unit, 0..32; all zero = plain deal
-    uint32_t unit_seq;     // ... this launch's number on its stream, written with the finish stamps
-    unsigned long long *unit_stamps;  // ... pinned host memory, 8 words: (unit_seq << 32) | s_memrealtime of a late workgroup of XCD x
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
     double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value

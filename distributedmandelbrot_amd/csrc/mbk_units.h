@@ -87,19 +87,8 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
     if (emit[2]) order[nregions + 3u + s_base[2] + s_cnt[2][wave] + (uint32_t)__popcll(m[2] & below)] = (by << 16) | bx;
 }
 
-// Which workgroup computes which unit.  Plain deal: workgroup j takes units j, j + G, ... (G = p.unit_stride: the grid size,
-// passed as an argument -- gridDim.x lives in the dispatch packet in host memory and would be re-read on every trip).
-// WEIGHTED deal (p.unit_w != 0): the hardware deals workgroup ids to the 8 XCDs in turn, every XCD works through its own ids,
-// and the XCDs of one chip do not run at one speed -- time stamps per workgroup (profiles/r04/units_trace_*.txt) show them
-// finishing the same share 5-10 % apart, the same XCDs slow on every tile, so a launch lasts as long as its slowest XCD and
-// the others idle ~6 % of it.  Moving work between XCDs at run time needs cross-XCD atomics, which cost ~25 ns each
-// chip-wide (units_pool_ab.txt: 1.5-2.7 x slower).  So the deal itself is skewed, with no atomic: the units up to S8 (all of
-// H, half of M) go unit j to workgroup j as before; behind them every XCD x (= id mod 8) lets only a_x of every 32 of its ids
-// take a unit, and the ids that do take the pool's units in id order -- unit S8 + rank, rank = the number of taking ids
-// before this one, a closed form of the eight a_x -- so that an XCD with a smaller a_x gets less of the pool.  The a_x come
-// from the host, which reads the finish stamps the late workgroups of every XCD left behind in the previous launches
-// (mbk_api.hip: units_feedback).  Scheduling only: every unit is computed exactly once whatever the weights are.
-// kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
+// Workgroup j: units j, j + G, ... (G = p.unit_stride: the grid size, passed as an argument -- gridDim.x lives in the
+// dispatch packet in host memory and would be re-read on every trip).  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
 // kStats (bytes-only instantiation): the kernel adds the tile's pixel-iterations and never-escaped count to args.stats itself --
 // per lane in registers over the wave's units, one reduction and two atomics per wave -- so that a DataChunk whose caller
 // wants bytes only writes no int32 counts and the statistics pass reads the 16 MiB of bytes only (what the finish-in-place
@@ -108,10 +97,8 @@ template <typename T, int kGroup, bool kCycle, bool kCounts, bool kBytes, bool k
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_units_kernel(TileArgs args, uint32_t qtab)
 {
     static_assert(!kStats || (!kCounts && kBytes), "fused statistics exist for the bytes-only instantiation");
-    // fused statistics, ONE 64-bit accumulator per lane (the heavy loops leave no register to spare at 8 waves per SIMD):
-    // pixel-iterations in bits 0..39 (< 2^31 per block, far fewer than 2^9 blocks per lane), never-escaped pixels from bit 40
-    unsigned long long tally = 0;
-    uint32_t acc = 0;                       // counts of the blocks the light path finished (<= 4 each), folded into tally after every unit
+    unsigned long long heavy_iters = 0;     // pixel-iterations / never-escaped pixels of the blocks computed by block_pixel
+    uint32_t heavy_never = 0, acc = 0;      // acc: counts of the blocks the light path finished (<= 4 each)
     const uint32_t never_cap = args.mrd > 1 ? (uint32_t)args.mrd - 1u : 0u;
     // The loop keeps the launch's arguments alive across a whole block, and the escape loops need their share of the 96
     // scalar registers that 8 waves per SIMD leave a wave.  What this kernel never uses is pinned to the value the host
@@ -130,56 +117,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t n_h = uniform_u32(p.order[n]), n_v = uniform_u32(p.order[n + 1u]), n_m = uniform_u32(p.order[n + 2u]);
     const uint32_t total = n_h + n_m + n_v;
     const uint32_t oscale = kCounts ? 4u : 1u;
-    // ---- the deal ----
-    uint32_t u = blockIdx.x;
-    bool weighted = false, stamp = false;
-    uint32_t my_x = 0u;
-    {
-        const uint32_t s8 = (n_h + n_m - (n_m >> 1)) & ~7u;     // static units: all of H, the first half of M (whole groups of 8 ids)
-        const uint32_t pool = total - s8;
-        uint32_t a[8], a_sum = 0u;
-#pragma unroll
-        for (uint32_t x = 0; x < 8u; ++x) {
-            a[x] = (args.unit_w[x >> 2] >> (8u * (x & 3u))) & 0xffu;
-            a[x] = a[x] > 32u ? 32u : a[x];
-            a_sum += a[x];
-        }
-        if (a_sum != 0u) {
-            const uint32_t cycles = (pool + a_sum - 1u) / a_sum;              // 256 ids (32 per XCD) per cycle
-            weighted = (unsigned long long)s8 + (unsigned long long)cycles * 256u <= p.unit_stride;   // else: the grid is too small, plain deal
-            if (weighted && u >= s8) {
-                const uint32_t jj = u - s8, x = jj & 7u, i = jj >> 3, cyc = i >> 5, s = i & 31u;
-                uint32_t rank = cyc * a_sum, mine = 0u;
-#pragma unroll
-                for (uint32_t y = 0; y < 8u; ++y) {
-                    rank += s < a[y] ? s : a[y];                        // taking ids of XCD y in this cycle before slot s
-                    rank += (y < x && s < a[y]) ? 1u : 0u;              // ... and at slot s, before this XCD
-                    mine = y == x ? a[y] : mine;
-                }
-                if (s >= mine || rank >= pool) return;                  // this id takes no unit
-                u = s8 + rank;
-                my_x = x;
-                stamp = cyc + 2u >= cycles;                             // a late workgroup of its XCD: leaves a finish stamp
-            } else if (weighted) {
-                my_x = u & 7u;
-                stamp = u + 512u >= n_h && u < n_h;                     // the last H workgroups of every XCD stamp too
-            }
-        }
-    }
-    for (; u < total; u += p.unit_stride) {
+    for (uint32_t u = blockIdx.x; u < total; u += p.unit_stride) {
         if (u < n_h + n_m) {
             const bool is_h = u < n_h;
             // (loads inside the loop follow this wave's own stores, so the compiler will not keep them on the scalar unit
             // by itself; the address is wave-uniform: say so)
             const uint32_t e = uniform_u32(is_h ? p.order[u] : p.order[n + 3u + (u - n_h)]);
             const uint32_t by = e >> 16, bx = e & 0xffffu;
-            if (kStats) {
-                tally += acc;
-                acc = 0u;
-            }
             const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h,
                                                                    bx < p.fast_bx_end && by < p.fast_by_end);
-            if (kStats && c >= 0) tally += c > 0 ? (unsigned long long)(uint32_t)c : (1ull << 40) + never_cap;
+            if (kStats && c >= 0) {
+                heavy_iters += c > 0 ? (uint32_t)c : never_cap;
+                heavy_never += c == 0 ? 1u : 0u;
+            }
         } else {
             const uint32_t v = uniform_u32(p.order[n - 1u - (u - n_h - n_m)]);
             const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
@@ -194,26 +144,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             int32_t cnt;
             while (escape_light_row<kCounts, kBytes, kStats>(ci, b0, col, p.re.step, p.re.start, cnt, cb, bb, off, 8u * oscale, qtab, mask, k, &acc) != 0u) {
                 // block k of the unit outlives the light path (the probe saw only its centre pixel): the whole block, exactly
-                if (kStats) {            // (folded first: nothing but `tally` is live across the heavy loops)
-                    tally += acc;
-                    acc = 0u;
-                }
                 const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, (bx0 + k) * 8u, by * 8u, lx, ly, false, true);
-                if (kStats && c >= 0) tally += c > 0 ? (unsigned long long)(uint32_t)c : (1ull << 40) + never_cap;
+                if (kStats && c >= 0) {
+                    heavy_iters += c > 0 ? (uint32_t)c : never_cap;
+                    heavy_never += c == 0 ? 1u : 0u;
+                }
                 if (++k >= 8u) break;
             }
         }
-        if (weighted) break;     // the weighted deal: one unit per workgroup
     }
-    // (what the end of the kernel needs of its arguments is read from the kernarg segment again -- TileArgs is the first
-    // argument -- instead of being kept in scalar registers across the heavy loops, which have none to spare)
-    const TileArgs *late = (const TileArgs *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
-    if (stamp && lane == 0u)     // (a posted 8-byte store to pinned host memory; the last writer of a slot is about its XCD's last)
-        late->unit_stamps[my_x] = ((unsigned long long)late->unit_seq << 32) | (unsigned long long)(uint32_t)wall_clock64();
     if (kStats) {
-        tally += acc;
-        const unsigned long long iters = wave_sum_u64(tally & ((1ull << 40) - 1ull)), never = wave_sum_u64(tally >> 40);
-        ReduceOut *out = &late->stats[blockIdx.x % kReduceSlots].r;
+        // (acc cannot wrap: <= 4 per block, and a wave handles far fewer than 2^29 blocks)
+        const unsigned long long iters = wave_sum_u64(heavy_iters + acc), never = wave_sum_u64((unsigned long long)heavy_never);
+        ReduceOut *out = &args.stats[blockIdx.x % kReduceSlots].r;
         if (lane == 0) {
             if (iters) atomicAdd(&out->pixel_iterations, iters);
             if (never) atomicAdd(&out->never_pixels, never);

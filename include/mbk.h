@@ -279,12 +279,6 @@ enum mbk_option {
                               probe pixels of the window is gone after 4 steps -- where there is little light area to batch, the
                               plain one-block-per-workgroup kernel (order 2) is the leaner one (cfg3: -0.7 %): 0 (always) ..
                               65536 [32768 = one half] */
-    MBK_OPT_UNITS_SKEW,    /* order 3: the weighted deal.  The hardware deals workgroup ids to the 8 XCDs in turn and the XCDs of one
-                              chip finish equal shares 5-10 % apart, so a launch lasts as long as its slowest XCD
-                              (profiles/r04/units_trace_*.txt).  [1]: behind the static units every XCD takes a_x of every 32 of its
-                              ids' worth of the remaining ones, the a_x following the finish stamps that the previous launches
-                              on the stream left in pinned memory (one step per launch); 0: plain deal; 2: the weighted path with even
-                              weights; 3..9: fixed uneven test patterns */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

@@ -98,10 +98,6 @@ PY
         timeout 600 python scripts/analyze_units_trace.py "$OUT/units_trace_$W.bin" >> "$OUT/units_trace_$W.txt" 2>&1
         cat "$OUT/units_trace_$W.txt"; rm -f "$OUT/units_trace_$W.bin"
       done;;
-  skew) for rep in 1 2; do for V in 0 2 1; do
-        b cfg2_skew${V}_$rep --no-cpu-baseline --no-extras --opt units_skew=$V
-      done; done
-      b cfg2_skew1_long --no-cpu-baseline --no-extras --opt units_skew=1 --warmup 600 --steps 600;;
   events) for rep in 1 2; do for W in cfg2 chunk_l1; do
         b ${W}_region_$rep --workload $W --no-cpu-baseline --no-extras --launch-events region
         b ${W}_perlaunch_$rep --workload $W --no-cpu-baseline --no-extras --launch-events per-launch
