@@ -28,7 +28,7 @@ KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MB
 # enum mbk_option (include/mbk.h), in order
 OPTIONS = {name: i for i, name in enumerate(
     ["order", "waves_per_wg", "group_steps", "exact_steps", "probe_steps", "scan_waves", "scan_xcd_map", "scan_col_period", "heavy_share",
-     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid", "prepass_overlap", "exact_long", "scan_inline", "wave_limit", "units_min_light"])}
+     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid", "prepass_overlap", "exact_long", "scan_inline", "wave_limit", "units_min_light", "xcd_balance"])}
 MBK_PRECISION_F32 = 0x1000
 MBK_LAZY_UNIFORM = 0x2000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
@@ -120,6 +120,8 @@ SIGNATURES = {
     "mbk_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "mbk_get_option": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "mbk_quantise_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "mbk_units_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "mbk_units_lookup": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mbk_reduce_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                     C.POINTER(mbk_stats)]),
     "mbk_worker_run": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint16, C.c_uint64, C.c_uint32,

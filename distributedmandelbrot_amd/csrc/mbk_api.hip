@@ -56,8 +56,15 @@ struct StreamScratch {
                                   // [0] longest deferred list (scan pass 2), [1] share of heavy blocks x 65536
     ReduceSlot *d_red = nullptr;  // mbk_reduce_counts on this (caller) stream: its own partial results, so that a
     ReduceSlot *h_red = nullptr;  // reduction on a caller stream never shares a buffer with a tile in flight on a slot
+    // kernel "units": the shares of the eight XCDs (mbk_units.h).  Launch number c (1-based) writes its time stamps into
+    // slot c % kStampSlots of h_stamps (pinned) and used the fractions in xcd_ring[c % kShareRing].
+    unsigned long long *h_stamps = nullptr;
+    double xcd_f[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
+    uint32_t xcd_issued = 0, xcd_consumed = 0;
+    struct SharesUsed { uint32_t seq; float f[8]; } xcd_ring[64] = {};
 };
 static const size_t kMaxStreamScratch = 64;
+static const uint32_t kStampSlots = 16, kShareRing = 64;
 
 // One in-flight tile of the host-buffer API: its own stream (so that the D2H of one slot overlaps the
 // kernel of the other), events, device result buffers and reduction scratch.
@@ -228,6 +235,7 @@ static void free_scratch(StreamScratch &sc)
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
     if (sc.h_hint) (void)hipHostFree(sc.h_hint);
+    if (sc.h_stamps) (void)hipHostFree(sc.h_stamps);
     if (sc.d_red) (void)hipFree(sc.d_red);
     if (sc.h_red) (void)hipHostFree(sc.h_red);
     sc = StreamScratch();
@@ -262,7 +270,57 @@ static int get_scratch(mbk_ctx *ctx, hipStream_t stream, StreamScratch **out)
 //   ring_possible               conservative rectangle test against | |c|^2 - 4 | < margin (kernel margins are
 //                               1e-9 fp64 / 1e-3 fp32 per pixel; the host test allows 1e-6 / 2e-3).
 static void set_window_facts(TileArgs &a, bool f32);
+static void shares_from_fractions(const double *f, uint32_t *cum);
 static double window_heavy_share(const TileArgs &a);
+
+// Kernel "units": new H fractions for the eight XCDs from the time stamps of the launches on this stream that have finished
+// since the last look (mbk_units.h).  A launch that dealt XCD x the fraction f_x of the H list and saw it deal its last
+// ids T_x after the launch's first workgroup started measures its speed as f_x / T_x; the fractions follow the normalised
+// speeds with a gain of 1/2, clamped to +-12 % of an even deal.  A slot whose 72 stamps do not all carry the launch's
+// number (still running, overwritten, a grid too small to reach the tail on the first trip) is skipped.
+static void xcd_shares_update(StreamScratch &sc)
+{
+    const unsigned long long kMask = 0xffffffffffffull;
+    uint32_t first = sc.xcd_issued >= kStampSlots ? sc.xcd_issued - kStampSlots + 1u : 1u;
+    first = std::max(first, sc.xcd_consumed + 1u);
+    for (uint32_t c = first; c <= sc.xcd_issued; ++c) {
+        const volatile unsigned long long *st = sc.h_stamps + (size_t)(c % kStampSlots) * mbk::kStampWords;
+        const StreamScratch::SharesUsed &used = sc.xcd_ring[c % kShareRing];
+        if (used.seq != c) continue;
+        unsigned long long v[mbk::kStampWords];
+        bool whole = true;
+        for (uint32_t i = 0; i < mbk::kStampWords; ++i) {
+            v[i] = st[i];
+            whole = whole && (v[i] >> 48) == (c & 0xffffu);
+        }
+        if (!whole) continue;
+        unsigned long long start = v[0] & kMask;
+        for (uint32_t x = 1; x < 8u; ++x)
+            if ((((v[x] & kMask) - start) & kMask) >> 47) start = v[x] & kMask;   // earlier (mod 2^48)
+        double T[8], tmin = 1e300, tmax = 0.0, speed[8], sum = 0.0;
+        for (uint32_t x = 0; x < 8u; ++x) {
+            unsigned long long last = 0;
+            for (uint32_t t = 0; t < mbk::kStampTail; ++t)
+                last = std::max(last, ((v[8u + x * mbk::kStampTail + t] & kMask) - start) & kMask);
+            T[x] = (double)last;
+            tmin = std::min(tmin, T[x]);
+            tmax = std::max(tmax, T[x]);
+        }
+        sc.xcd_consumed = c;
+        if (tmin < 1000.0 || tmax > 1.25 * tmin) continue;   // under 10 us, or nothing a share could explain
+        for (uint32_t x = 0; x < 8u; ++x) {
+            speed[x] = (double)used.f[x] / T[x];
+            sum += speed[x];
+        }
+        double fs = 0.0;
+        for (uint32_t x = 0; x < 8u; ++x) {
+            const double f = 0.5 * sc.xcd_f[x] + 0.5 * speed[x] / sum;
+            sc.xcd_f[x] = std::min(0.14, std::max(0.11, f));
+            fs += sc.xcd_f[x];
+        }
+        for (uint32_t x = 0; x < 8u; ++x) sc.xcd_f[x] /= fs;
+    }
+}
 
 // Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
 // (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
@@ -322,9 +380,9 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                 sc->done_valid[k] = false;
             }
             sc->order_cap = 0;
-            // list | 3 counters | middle-class list (classify_blocks_kernel)
+            // list | 3 counters | middle-class list (classify_blocks_kernel) | XCD shares of the units kernel (64-byte aligned)
             for (int k = 0; k < 2; ++k)
-                MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], (2u * (size_t)grid.x + 3u) * sizeof(uint32_t)));
+                MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], (2u * (size_t)grid.x + 3u + 16u + mbk::kPlanWords) * sizeof(uint32_t)));
             sc->order_cap = grid.x;
         }
         // Pre-pass of THIS launch on the aux stream: it depends on the window only, not on anything the caller's
@@ -339,10 +397,34 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         if (overlap && sc->done_valid[k]) MBK_HIP(ctx, hipStreamWaitEvent(sc->aux, sc->ev_done[k], 0));
         // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
-        if (units)
+        if (units) {
             hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a, grid.x,
                                (int32_t)probe_steps, ord, cursors);
-        else
+            // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
+            // stream, 2 a fixed uneven deal (tests)
+            const uint32_t balance = ctx->opt[MBK_OPT_XCD_BALANCE];
+            static const double kUneven[8] = {0.110, 0.140, 0.125, 0.120, 0.130, 0.125, 0.115, 0.135};
+            if (balance == 1u && !sc->h_stamps) {
+                MBK_HIP(ctx, hipHostMalloc((void **)&sc->h_stamps, (size_t)kStampSlots * mbk::kStampWords * sizeof(unsigned long long),
+                                           hipHostMallocDefault));
+                std::memset(sc->h_stamps, 0xff, (size_t)kStampSlots * mbk::kStampWords * sizeof(unsigned long long));
+            }
+            if (balance == 1u) xcd_shares_update(*sc);
+            mbk::XcdShares w;
+            double f[8];
+            const uint32_t seq = ++sc->xcd_issued;
+            StreamScratch::SharesUsed &used = sc->xcd_ring[seq % kShareRing];
+            used.seq = seq;
+            for (uint32_t x = 0; x < 8u; ++x) {
+                f[x] = balance == 1u ? sc->xcd_f[x] : (balance == 2u ? kUneven[x] : 0.125);
+                used.f[x] = (float)f[x];
+            }
+            shares_from_fractions(f, w.cum);
+            a.plan = ord + ((2u * (size_t)grid.x + 3u + 15u) & ~(size_t)15u);
+            a.stamps = balance == 1u ? sc->h_stamps + (size_t)(seq % kStampSlots) * mbk::kStampWords : nullptr;
+            a.stamp_tag = seq & 0xffffu;
+            hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)cursors, w, (uint32_t *)a.plan);
+        } else
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a,
                            grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
         if (overlap) {
@@ -365,7 +447,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         const double est = (double)grid.x * (share + (1.0 - share) / 8.0);
         const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
         uint32_t g = (uint32_t)std::min<double>((double)grid.x, est * 1.15 + 2048.0);
-        g = std::max(g, std::min(grid.x, cus * 64u));
+        g = (std::max(g, std::min(grid.x, cus * 64u)) + 7u) & ~7u;   // a multiple of 8: id mod 8 = workgroup mod 8 = the XCD
         a.unit_stride = g;
         uint32_t qtab = 0u;   // quantised bytes of counts 1..4, packed (the light path's table)
         if (a.bytes && a.mrd > 0)
@@ -903,7 +985,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u};
+        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 1u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1343,6 +1425,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;
         case MBK_OPT_UNITS_MIN_LIGHT: ok = value <= 65536u; break;
+        case MBK_OPT_XCD_BALANCE: ok = value <= 2u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");
@@ -1360,6 +1443,42 @@ int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value)
     }
     if (option < 0 || option >= MBK_OPT_COUNT_) return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     *value = ctx->opt[option];
+    return MBK_OK;
+}
+
+// The share arithmetic of the units kernel on the host (no device, no context): the very functions units_plan_kernel and
+// tile_units_kernel call, for the CPU tests.
+static void shares_from_fractions(const double *f, uint32_t *cum)
+{
+    double c = 0.0;
+    for (uint32_t x = 0; x < 8u; ++x) {
+        c += f[x];
+        cum[x] = x == 7u ? (1u << 24) : (uint32_t)std::lround(std::min(1.0, std::max(0.0, c)) * (double)(1u << 24));
+    }
+}
+
+int mbk_units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const double *fractions, uint32_t *plan)
+{
+    if (!fractions || !plan) return MBK_ERR_INVALID;
+    if ((uint64_t)n_h + n_v + n_m > 0x7fffffffull) return MBK_ERR_INVALID;
+    uint32_t cum[8];
+    shares_from_fractions(fractions, cum);
+    mbk::units_plan(n_h, n_v, n_m, cum, plan);
+    return MBK_OK;
+}
+
+int mbk_units_lookup(const uint32_t *plan, uint32_t id, uint32_t *list, uint32_t *index)
+{
+    if (!plan || !list || !index) return MBK_ERR_INVALID;
+    const uint32_t x = id & 7u;
+    bool is_h = false;
+    uint32_t i = 0;
+    *list = 0u;
+    *index = 0u;
+    if (id >= plan[2] || !mbk::units_lookup(id, plan[3], plan[4], plan[8u + x], plan[16u + x], plan[24u + x], plan[32u + x], is_h, i))
+        return MBK_OK;
+    *list = is_h ? 1u : (i < plan[1] ? 2u : 3u);
+    *index = is_h ? i : (i < plan[1] ? i : i - plan[1]);
     return MBK_OK;
 }
 

@@ -59,6 +59,9 @@ struct TileArgs {
     uint32_t ngrid;        // with `order`: the grid size (= list length); the counters sit at order[ngrid .. ngrid + 3)
     uint32_t order_mid;    // with `order`: 1 = a middle class was built (MBK_OPT_PROBE_MID <= probe depth)
     uint32_t unit_stride;  // kernel "units" (mbk_units.h): the grid size G; workgroup j takes units j, j + G, ...
+    uint32_t stamp_tag;    // kernel "units": 16-bit launch number written into the top of every time stamp
+    const uint32_t *plan;  // kernel "units": the shares of the eight XCDs (units_plan_kernel; layout in mbk_units.h)
+    unsigned long long *stamps;  // kernel "units", may be null: pinned host memory for this launch's time stamps
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null
     double *smooth;       // may be null: continuous escape-time value (BASELINE cfg5), see smooth_value

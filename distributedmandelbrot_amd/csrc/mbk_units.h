@@ -87,8 +87,76 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
     if (emit[2]) order[nregions + 3u + s_base[2] + s_cnt[2][wave] + (uint32_t)__popcll(m[2] & below)] = (by << 16) | bx;
 }
 
-// Workgroup j: units j, j + G, ... (G = p.unit_stride: the grid size, passed as an argument -- gridDim.x lives in the
-// dispatch packet in host memory and would be re-read on every trip).  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
+// ---- Shares of the eight XCDs ------------------------------------------------------------------------------------------
+// The hardware deals workgroup ids to the XCDs in turn (id mod 8 -- profiles/microbench/units_trace.hip read XCC_ID), every XCD
+// works through its own ids, and the XCDs of one chip do not run at one speed: equal shares end 2-10 % apart and the launch
+// lasts as long as its slowest XCD (profiles/NOTES.md 2b).  Atomics across XCDs are far too slow to rebalance at run time
+// (units_pool_ab.txt), so the shares themselves are uneven: XCD x takes h[x] entries of the H list, then l[x] of the light
+// list (M entries, then V units).  Workgroup id 8 j + x finds its unit without atomics: entry 8 j + x while j is below the
+// smallest share (the even deal, nearly all ids), and behind that the rest of the list in one contiguous piece per XCD
+// (entry base[x] + j).  The host sets the H fractions from what earlier launches on the stream reported (mbk_api.hip: the time at
+// which every XCD dealt its last ids, kStampTail plain stores per XCD into pinned memory); the counts are known only on the
+// device, so a one-thread kernel behind classify turns fractions into shares.  Which XCD computes a block changes when it
+// is computed, never what is stored.
+constexpr uint32_t kStampTail = 8;                      // ids per XCD, from the end, that leave a time stamp
+constexpr uint32_t kStampWords = 8u + 8u * kStampTail;  // per launch: first id of every XCD, then the tails
+constexpr uint32_t kPlanWords = 40;  // [0] H entries [1] M entries [2] ids in all (8 per XCD round) [3] min h [4] min l
+                                     // [8..16) h[x]  [16..24) l[x]  [24..32) H base[x]  [32..40) light base[x]
+struct XcdShares { uint32_t cum[8]; };   // H list: share of XCDs 0..x, in 2^-24 (cum[7] = 2^24)
+
+// (host and device: mbk_units_plan / mbk_units_lookup of the C ABI run the same lines for the CPU tests)
+__host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const uint32_t *cum, uint32_t *plan)
+{
+    const uint32_t n_l = n_m + n_v, total = n_h + n_l;
+    uint32_t h[8], l[8], prev = 0, slots = (total + 7u) >> 3;
+    for (uint32_t x = 0; x < 8u; ++x) {
+        uint32_t c = x == 7u ? n_h : (uint32_t)(((unsigned long long)n_h * cum[x]) >> 24);
+        c = c < prev ? prev : (c > n_h ? n_h : c);
+        h[x] = c - prev;
+        prev = c;
+        slots = slots > h[x] ? slots : h[x];
+    }
+    // light entries: every XCD is filled up to `slots` ids, the first XCDs first (8 slots >= total: the list fits) -- an
+    // XCD with a small H share takes more of them
+    uint32_t left = n_l, hmin = 0xffffffffu, lmin = 0xffffffffu;
+    for (uint32_t x = 0; x < 8u; ++x) {
+        const uint32_t room = slots - h[x];
+        l[x] = room < left ? room : left;
+        left -= l[x];
+        hmin = hmin < h[x] ? hmin : h[x];
+        lmin = lmin < l[x] ? lmin : l[x];
+    }
+    plan[0] = n_h; plan[1] = n_m; plan[2] = slots * 8u; plan[3] = hmin; plan[4] = lmin; plan[5] = plan[6] = plan[7] = 0u;
+    uint32_t hb = 8u * hmin, lb = 8u * lmin;   // the contiguous pieces start behind the evenly dealt part
+    for (uint32_t x = 0; x < 8u; ++x) {
+        plan[8u + x] = h[x];
+        plan[16u + x] = l[x];
+        plan[24u + x] = hb - hmin;            // entry of id (x, j >= hmin): base + j
+        plan[32u + x] = lb - lmin;
+        hb += h[x] - hmin;
+        lb += l[x] - lmin;
+    }
+}
+
+// Id u = 8 j + x: false = none (beyond this XCD's shares; so are all later ids of the XCD), else the entry of the H list
+// (is_h) or of the light list it takes.
+__host__ __device__ __forceinline__ bool units_lookup(uint32_t u, uint32_t hmin, uint32_t lmin, uint32_t h_x, uint32_t l_x,
+                                                      uint32_t hbase_x, uint32_t lbase_x, bool &is_h, uint32_t &i)
+{
+    const uint32_t x = u & 7u, j = u >> 3, k = j - h_x;
+    is_h = j < h_x;
+    if (!is_h && k >= l_x) return false;
+    i = is_h ? (j < hmin ? u : hbase_x + j) : (k < lmin ? 8u * k + x : lbase_x + k);
+    return true;
+}
+
+__global__ void units_plan_kernel(const uint32_t *counters, XcdShares w, uint32_t *plan)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) units_plan(counters[0], counters[1], counters[2], w.cum, plan);
+}
+
+// Workgroup b: ids b, b + G, ... (G = p.unit_stride: the grid size, a multiple of 8, passed as an argument -- gridDim.x
+// lives in the dispatch packet in host memory and would be re-read on every trip); id 8 j + x is the j-th of XCD x.  kGroup: 16 (fp64) / 8 (fp32), as in tile_asm_kernel.
 // kStats (bytes-only instantiation): the kernel adds the tile's pixel-iterations and never-escaped count to args.stats itself --
 // per lane in registers over the wave's units, one reduction and two atomics per wave -- so that a DataChunk whose caller
 // wants bytes only writes no int32 counts and the statistics pass reads the 16 MiB of bytes only (what the finish-in-place
@@ -114,15 +182,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t n = p.ngrid;
-    const uint32_t n_h = uniform_u32(p.order[n]), n_v = uniform_u32(p.order[n + 1u]), n_m = uniform_u32(p.order[n + 2u]);
-    const uint32_t total = n_h + n_m + n_v;
+    const uint32_t x = blockIdx.x & 7u;                      // this workgroup's XCD (the stride is a multiple of 8)
+    if (args.stamps) {
+        // when did every XCD start on its first and deal its last ids?  (100 MHz wall clock, launch number on top)
+        const uint32_t j0 = blockIdx.x >> 3, slots = uniform_u32(args.plan[2]) >> 3;
+        const unsigned long long t = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)args.stamp_tag << 48);
+        if (lane == 0 && j0 == 0u) args.stamps[x] = t;
+        if (lane == 0 && j0 < slots && j0 + kStampTail >= slots) args.stamps[8u + x * kStampTail + (j0 + kStampTail - slots)] = t;
+    }
     const uint32_t oscale = kCounts ? 4u : 1u;
-    for (uint32_t u = blockIdx.x; u < total; u += p.unit_stride) {
-        if (u < n_h + n_m) {
-            const bool is_h = u < n_h;
-            // (loads inside the loop follow this wave's own stores, so the compiler will not keep them on the scalar unit
-            // by itself; the address is wave-uniform: say so)
-            const uint32_t e = uniform_u32(is_h ? p.order[u] : p.order[n + 3u + (u - n_h)]);
+    for (uint32_t u = blockIdx.x;; u += p.unit_stride) {
+        // (the shares are read anew on every trip -- a second trip is rare -- so that nothing of them stays in scalar
+        // registers across a block; loads inside the loop follow this wave's own stores, so the compiler will not keep
+        // them on the scalar unit by itself: the addresses are wave-uniform, say so)
+        const uint32_t *pl = args.plan;
+        const uint32_t n_m = uniform_u32(pl[1]), total = uniform_u32(pl[2]), hmin = uniform_u32(pl[3]), lmin = uniform_u32(pl[4]);
+        const uint32_t h_x = uniform_u32(pl[8u + x]), l_x = uniform_u32(pl[16u + x]);
+        const uint32_t hbase_x = uniform_u32(pl[24u + x]), lbase_x = uniform_u32(pl[32u + x]);
+        if (u >= total) break;
+        bool is_h;
+        uint32_t i;    // index into the H list / the light list (M entries, then V units)
+        if (!units_lookup(u, hmin, lmin, h_x, l_x, hbase_x, lbase_x, is_h, i)) break;
+        if (is_h || i < n_m) {
+            const uint32_t e = uniform_u32(is_h ? p.order[i] : p.order[n + 3u + i]);
             const uint32_t by = e >> 16, bx = e & 0xffffu;
             const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h,
                                                                    bx < p.fast_bx_end && by < p.fast_by_end);
@@ -131,7 +213,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 heavy_never += c == 0 ? 1u : 0u;
             }
         } else {
-            const uint32_t v = uniform_u32(p.order[n - 1u - (u - n_h - n_m)]);
+            const uint32_t v = uniform_u32(p.order[n - 1u - (i - n_m)]);
             const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
             // the unit's imaginary coordinate (regular formula: classify files under V only blocks inside the fast region)
             const T ci = (T)((double)(p.row0 + by * 8u + ly) * p.im.step + p.im.start);

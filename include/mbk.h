@@ -279,6 +279,11 @@ enum mbk_option {
                               probe pixels of the window is gone after 4 steps -- where there is little light area to batch, the
                               plain one-block-per-workgroup kernel (order 2) is the leaner one (cfg3: -0.7 %): 0 (always) ..
                               65536 [32768 = one half] */
+    MBK_OPT_XCD_BALANCE,   /* order 3: shares of the eight XCDs in the units kernel's list of heavy blocks.  The XCDs of one chip run
+                              2-10 % apart and the hardware deals them equal numbers of workgroups, so a launch lasts as long as
+                              its slowest XCD: 0 even shares, [1] shares that follow the time stamps earlier launches on the same
+                              stream left in pinned memory (72 stores per launch; the first launch on a stream is even), 2 a fixed
+                              uneven deal (tests).  Changes when a block is computed, never what is stored */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
@@ -286,6 +291,14 @@ enum mbk_option {
 #define MBK_INFO_SCAN_WG_PER_CU 100
 int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value);
 int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value);
+
+/* Diagnostics of the units kernel's deal across the eight XCDs (MBK_OPT_XCD_BALANCE), on the host, without a device or a
+ * context: the functions the kernels call.  mbk_units_plan: the shares for a list of n_h heavy entries, n_m middle entries
+ * and n_v row units under the H fractions `fractions[8]` (sum 1) -> plan[40] ([2] = number of workgroup ids, [8 + x] /
+ * [16 + x] = heavy / light entries of XCD x).  mbk_units_lookup: what workgroup id `id` computes: *list = 0 nothing, 1 heavy
+ * entry *index, 2 middle entry *index, 3 row unit *index.  Every entry of every list is taken by exactly one id. */
+int mbk_units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const double *fractions, uint32_t *plan);
+int mbk_units_lookup(const uint32_t *plan, uint32_t id, uint32_t *list, uint32_t *index);
 
 /* The quantiser alone, on the device: h_bytes[i] = uint8(ceil(h_counts[i] * 256 / mrd)) for n host counts
  * (WorkerCUDA.py:96-98; each count must lie in [0, mrd-1], which is what calc_mb_value returns).

@@ -98,6 +98,10 @@ PY
         timeout 600 python scripts/analyze_units_trace.py "$OUT/units_trace_$W.bin" >> "$OUT/units_trace_$W.txt" 2>&1
         cat "$OUT/units_trace_$W.txt"; rm -f "$OUT/units_trace_$W.bin"
       done;;
+  skew) [ -x build/units_skew ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip 2> "$OUT/build_units_skew.log"
+      for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.25}; do
+        timeout 120 build/units_skew ${A//,/ } > "$OUT/units_skew_${A//,/_}.txt" 2>&1; tail -4 "$OUT/units_skew_${A//,/_}.txt"
+      done;;
   events) for rep in 1 2; do for W in cfg2 chunk_l1; do
         b ${W}_region_$rep --workload $W --no-cpu-baseline --no-extras --launch-events region
         b ${W}_perlaunch_$rep --workload $W --no-cpu-baseline --no-extras --launch-events per-launch
@@ -108,7 +112,7 @@ PY
         b cfg2_wg1_$rep --kernel group --no-cpu-baseline --no-extras
         b cfg2_wg4_$rep --kernel group --no-cpu-baseline --no-extras --opt waves_per_wg=4
       done;;
-  ab) for rep in 1 2; do for W in cfg2 chunk_l1 cfg3; do
+  ab) for rep in 1 2; do for W in ${ABW:-cfg2 chunk_l1 cfg3}; do
         b ${W}_base_$rep --workload $W --no-cpu-baseline --no-extras
         b ${W}_${ARG%%=*}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"
       done; done;;

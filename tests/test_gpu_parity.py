@@ -411,6 +411,8 @@ OPTION_MATRIX = [
     ("group", {"order": 3, "units_min_light": 0}), ("group", {"order": 3, "cycle_detect": 0, "units_min_light": 0}),
     ("default", {"order": 3, "exact_steps": 3, "probe_steps": 8, "units_min_light": 0}), ("group", {"order": 3, "units_min_light": 65536}),
     ("group", {"order": 2}), ("group", {"order": 3, "group_steps": 8}), ("group", {"order": 3, "waves_per_wg": 2}),
+    ("group", {"order": 3, "xcd_balance": 0}), ("group", {"order": 3, "xcd_balance": 2, "units_min_light": 0}),
+    ("default", {"xcd_balance": 2, "cycle_detect": 0}),
 ]
 
 
@@ -445,7 +447,7 @@ def test_units_order_every_output_set_and_shape(oracle):
     mbk_view_launch on device buffers, on views that exercise what the unit path must get right: rows that are no multiple
     of 8 and a window that stops short of the view (ragged edges -> class M), a window with an offset into a larger view,
     units in which the probe misses a long-lived block (the antenna: y = 0 midway between two probe rows), a tile with no
-    set in it, a tile that is all set, and mrd at the light path's step limits."""
+    set in it, a tile that is all set, and mrd at the light path's step limits; under both uneven deals across the XCDs."""
     import torch
     from distributedmandelbrot_amd import MandelbrotDevice
     cases = [
@@ -463,6 +465,9 @@ def test_units_order_every_output_set_and_shape(oracle):
         dev.set_option("units_min_light", 0)      # every window through the units kernel, also the ones it is not the default for
         for cyc in (1, 0):
             dev.set_option("cycle_detect", cyc)
+            # the deal across the XCDs: shares that follow the time stamps of the launches before (they move while this
+            # loop runs), then a fixed uneven deal
+            dev.set_option("xcd_balance", 1 if cyc else 2)
             for view, window, mrd in cases:
                 col0, row0, ncols, nrows = window if window else (0, 0, view.width, view.height)
                 for precision in ("f64", "f32"):
