@@ -625,6 +625,8 @@ def main():
     my_finish = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    # (units kernel, MBK_OPT_XCD_BALANCE: what share of a tile's heavy blocks every XCD was getting when the region ended)
+    xcd_after_timed = dev.xcd_shares() if not fake and hasattr(dev, "xcd_shares") else None
 
     never = 0
     if queue_mode:
@@ -779,6 +781,7 @@ def main():
                "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz,
                "cycle_leg_error": cyc_err,
                "occupancy_api_wg_per_cu": device_info.get("scan_occupancy"),
+               "xcd_shares": xcd_after_timed,
                "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                            ("bench.py self-launch" if "MBK_BENCH_RUN_ID" in os.environ else "single process"),
                "oversubscribed": bool(args.oversubscribe),

@@ -423,7 +423,8 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             a.plan = ord + ((2u * (size_t)grid.x + 3u + 15u) & ~(size_t)15u);
             a.stamps = balance == 1u ? sc->h_stamps + (size_t)(seq % kStampSlots) * mbk::kStampWords : nullptr;
             a.stamp_tag = seq & 0xffffu;
-            hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)cursors, w, (uint32_t *)a.plan);
+            hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)cursors, w, a.stamps ? 1u : 0u,
+                               (uint32_t *)a.plan);
         } else
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a,
                            grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
@@ -1441,6 +1442,15 @@ int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value)
         *value = (uint32_t)ctx->scan_occ[k >> 1][k & 1];
         return MBK_OK;
     }
+    if (option >= MBK_INFO_XCD_SHARE && option < MBK_INFO_XCD_SHARE + 10) {
+        // the stream whose units launches have left the most time stamps so far
+        const StreamScratch *best = nullptr;
+        for (const StreamScratch &sc : ctx->scratch)
+            if (!best || sc.xcd_consumed > best->xcd_consumed) best = &sc;
+        const int k = option - MBK_INFO_XCD_SHARE;
+        *value = !best ? 0u : k < 8 ? (uint32_t)std::lround(best->xcd_f[k] * 1048576.0) : k == 8 ? best->xcd_consumed : best->xcd_issued;
+        return MBK_OK;
+    }
     if (option < 0 || option >= MBK_OPT_COUNT_) return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     *value = ctx->opt[option];
     return MBK_OK;
@@ -1463,7 +1473,7 @@ int mbk_units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const double *fract
     if ((uint64_t)n_h + n_v + n_m > 0x7fffffffull) return MBK_ERR_INVALID;
     uint32_t cum[8];
     shares_from_fractions(fractions, cum);
-    mbk::units_plan(n_h, n_v, n_m, cum, plan);
+    mbk::units_plan(n_h, n_v, n_m, cum, 0u, plan);
     return MBK_OK;
 }
 

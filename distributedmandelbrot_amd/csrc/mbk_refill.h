@@ -81,6 +81,17 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Element i of a list that an EARLIER kernel wrote and this launch only reads (dispatch lists, XCD shares), with a scalar load
+// wherever the code stands: the compiler turns an ordinary uniform load that follows the wave's own stores into a vector
+// load plus readfirstlane (several hundred ns more per unit), and is free to keep "uniform" values in vector registers.
+__device__ __forceinline__ uint32_t scalar_load_u32(const uint32_t *list, uint32_t i)
+{
+    uint32_t v;
+    const uint32_t *a = list + i;   // (uniform by construction; a readfirstlane here makes the compiler park it in a VGPR)
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(a) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1) {

@@ -101,11 +101,12 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
 constexpr uint32_t kStampTail = 8;                      // ids per XCD, from the end, that leave a time stamp
 constexpr uint32_t kStampWords = 8u + 8u * kStampTail;  // per launch: first id of every XCD, then the tails
 constexpr uint32_t kPlanWords = 40;  // [0] H entries [1] M entries [2] ids in all (8 per XCD round) [3] min h [4] min l
+                                     // [5] 1 = this launch leaves time stamps
                                      // [8..16) h[x]  [16..24) l[x]  [24..32) H base[x]  [32..40) light base[x]
 struct XcdShares { uint32_t cum[8]; };   // H list: share of XCDs 0..x, in 2^-24 (cum[7] = 2^24)
 
 // (host and device: mbk_units_plan / mbk_units_lookup of the C ABI run the same lines for the CPU tests)
-__host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const uint32_t *cum, uint32_t *plan)
+__host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const uint32_t *cum, uint32_t stamps, uint32_t *plan)
 {
     const uint32_t n_l = n_m + n_v, total = n_h + n_l;
     uint32_t h[8], l[8], prev = 0, slots = (total + 7u) >> 3;
@@ -126,7 +127,7 @@ __host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t 
         hmin = hmin < h[x] ? hmin : h[x];
         lmin = lmin < l[x] ? lmin : l[x];
     }
-    plan[0] = n_h; plan[1] = n_m; plan[2] = slots * 8u; plan[3] = hmin; plan[4] = lmin; plan[5] = plan[6] = plan[7] = 0u;
+    plan[0] = n_h; plan[1] = n_m; plan[2] = slots * 8u; plan[3] = hmin; plan[4] = lmin; plan[5] = stamps; plan[6] = plan[7] = 0u;
     uint32_t hb = 8u * hmin, lb = 8u * lmin;   // the contiguous pieces start behind the evenly dealt part
     for (uint32_t x = 0; x < 8u; ++x) {
         plan[8u + x] = h[x];
@@ -150,9 +151,48 @@ __host__ __device__ __forceinline__ bool units_lookup(uint32_t u, uint32_t hmin,
     return true;
 }
 
-__global__ void units_plan_kernel(const uint32_t *counters, XcdShares w, uint32_t *plan)
+__global__ void units_plan_kernel(const uint32_t *counters, XcdShares w, uint32_t stamps, uint32_t *plan)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) units_plan(counters[0], counters[1], counters[2], w.cum, plan);
+    if (threadIdx.x == 0 && blockIdx.x == 0) units_plan(counters[0], counters[1], counters[2], w.cum, stamps, plan);
+}
+
+// The nine words of the plan a workgroup of XCD x needs, with scalar loads issued together (scalar_load_u32's comment)
+__device__ __forceinline__ void load_shares(const uint32_t *plan, uint32_t x, uint32_t &n_m, uint32_t &total, uint32_t &hmin,
+                                            uint32_t &lmin, uint32_t &stamps, uint32_t &h_x, uint32_t &l_x, uint32_t &hbase_x,
+                                            uint32_t &lbase_x)
+{
+    const uint32_t *pl = plan, *px = plan + x;      // (kernel argument + workgroup id: scalar registers as they stand)
+    asm volatile("s_load_dword %0, %9, 0x4\n\t"
+                 "s_load_dword %1, %9, 0x8\n\t"
+                 "s_load_dword %2, %9, 0xc\n\t"
+                 "s_load_dword %3, %9, 0x10\n\t"
+                 "s_load_dword %4, %9, 0x14\n\t"
+                 "s_load_dword %5, %10, 0x20\n\t"
+                 "s_load_dword %6, %10, 0x40\n\t"
+                 "s_load_dword %7, %10, 0x60\n\t"
+                 "s_load_dword %8, %10, 0x80\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(n_m), "=&s"(total), "=&s"(hmin), "=&s"(lmin), "=&s"(stamps), "=&s"(h_x), "=&s"(l_x), "=&s"(hbase_x),
+                   "=&s"(lbase_x)
+                 : "s"(pl), "s"(px)
+                 : "memory");
+}
+
+// One time stamp for the host's shares (100 MHz wall clock, launch number on top) into word `slot` of the launch's record.
+// Reached by 72 workgroups of a launch: the two arguments are fetched HERE, from the kernel argument segment, and the lane
+// number is derived here, so that none of it occupies a register anywhere else.
+__device__ __forceinline__ void leave_stamp(uint32_t slot)
+{
+    unsigned long long base;
+    uint32_t tag;
+    asm volatile("s_load_dwordx2 %0, %2, %3\n\t"
+                 "s_load_dword %1, %2, %4\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(base), "=&s"(tag)
+                 : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(offsetof(TileArgs, stamps)), "n"(offsetof(TileArgs, stamp_tag))
+                 : "memory");
+    if (__lane_id() == 0)
+        reinterpret_cast<unsigned long long *>(base)[slot] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)tag << 48);
 }
 
 // Workgroup b: ids b, b + G, ... (G = p.unit_stride: the grid size, a multiple of 8, passed as an argument -- gridDim.x
@@ -183,28 +223,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t lx = lane & 7u, ly = lane >> 3;
     const uint32_t n = p.ngrid;
     const uint32_t x = blockIdx.x & 7u;                      // this workgroup's XCD (the stride is a multiple of 8)
-    if (args.stamps) {
-        // when did every XCD start on its first and deal its last ids?  (100 MHz wall clock, launch number on top)
-        const uint32_t j0 = blockIdx.x >> 3, slots = uniform_u32(args.plan[2]) >> 3;
-        const unsigned long long t = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)args.stamp_tag << 48);
-        if (lane == 0 && j0 == 0u) args.stamps[x] = t;
-        if (lane == 0 && j0 < slots && j0 + kStampTail >= slots) args.stamps[8u + x * kStampTail + (j0 + kStampTail - slots)] = t;
-    }
     const uint32_t oscale = kCounts ? 4u : 1u;
     for (uint32_t u = blockIdx.x;; u += p.unit_stride) {
         // (the shares are read anew on every trip -- a second trip is rare -- so that nothing of them stays in scalar
-        // registers across a block; loads inside the loop follow this wave's own stores, so the compiler will not keep
-        // them on the scalar unit by itself: the addresses are wave-uniform, say so)
-        const uint32_t *pl = args.plan;
-        const uint32_t n_m = uniform_u32(pl[1]), total = uniform_u32(pl[2]), hmin = uniform_u32(pl[3]), lmin = uniform_u32(pl[4]);
-        const uint32_t h_x = uniform_u32(pl[8u + x]), l_x = uniform_u32(pl[16u + x]);
-        const uint32_t hbase_x = uniform_u32(pl[24u + x]), lbase_x = uniform_u32(pl[32u + x]);
+        // registers across a block)
+        uint32_t n_m, total, hmin, lmin, stamps, h_x, l_x, hbase_x, lbase_x;
+        load_shares(args.plan, x, n_m, total, hmin, lmin, stamps, h_x, l_x, hbase_x, lbase_x);
+        if (stamps && u < p.unit_stride) {
+            // first trip: the first workgroup of every XCD and its last kStampTail tell the host when they started
+            const uint32_t j0 = u >> 3, slots = total >> 3;
+            if (j0 == 0u) leave_stamp(x);
+            if (j0 < slots && j0 + kStampTail >= slots) leave_stamp(8u + x * kStampTail + (j0 + kStampTail - slots));
+        }
         if (u >= total) break;
         bool is_h;
         uint32_t i;    // index into the H list / the light list (M entries, then V units)
         if (!units_lookup(u, hmin, lmin, h_x, l_x, hbase_x, lbase_x, is_h, i)) break;
         if (is_h || i < n_m) {
-            const uint32_t e = uniform_u32(is_h ? p.order[i] : p.order[n + 3u + i]);
+            const uint32_t e = scalar_load_u32(p.order, is_h ? i : n + 3u + i);
             const uint32_t by = e >> 16, bx = e & 0xffffu;
             const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h,
                                                                    bx < p.fast_bx_end && by < p.fast_by_end);
@@ -213,7 +249,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 heavy_never += c == 0 ? 1u : 0u;
             }
         } else {
-            const uint32_t v = uniform_u32(p.order[n - 1u - (i - n_m)]);
+            const uint32_t v = scalar_load_u32(p.order, n - 1u - (i - n_m));
             const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
             // the unit's imaginary coordinate (regular formula: classify files under V only blocks inside the fast region)
             const T ci = (T)((double)(p.row0 + by * 8u + ly) * p.im.step + p.im.start);

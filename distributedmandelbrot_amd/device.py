@@ -149,6 +149,16 @@ class MandelbrotDevice:
             out[name] = int(v.value)
         return out
 
+    def xcd_shares(self) -> dict:
+        """MBK_OPT_XCD_BALANCE = 1: the shares of the heavy list the eight XCDs currently get (an even deal is 0.125 each), the
+        number of the last units launch whose time stamps were read, and the units launches issued."""
+        vals = []
+        for k in range(10):
+            v = C.c_uint32(0)
+            self._check(self._lib.mbk_get_option(self._h, 110 + k, C.byref(v)))
+            vals.append(int(v.value))
+        return {"shares": [round(v / 1048576.0, 5) for v in vals[:8]], "last_launch_read": vals[8], "units_launches": vals[9]}
+
     def quantise_counts(self, counts: np.ndarray, mrd: int) -> np.ndarray:
         """The device's quantiser alone (WorkerCUDA.py:96-98) on host int32 counts in [0, mrd-1]."""
         counts = np.ascontiguousarray(counts, dtype=np.int32)

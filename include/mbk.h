@@ -289,6 +289,9 @@ enum mbk_option {
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
  * four scan-path kernels, in single-wave workgroups per CU: +0 f64 scan, +1 f64 heavy, +2 f32 scan, +3 f32 heavy. */
 #define MBK_INFO_SCAN_WG_PER_CU 100
+/* MBK_OPT_XCD_BALANCE = 1, of the stream that has reported most: +0..+7 the share of XCD x of the heavy list (x 2^20; an even
+ * deal is 131072), +8 the number of the last launch whose time stamps were read, +9 the units launches issued. */
+#define MBK_INFO_XCD_SHARE 110
 int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value);
 int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value);
 

@@ -12,6 +12,8 @@
 #   emulate      scripts/scale_emulate.py -> scale_prediction.json
 #   benches      the other bench lines (kernels, workloads)
 #   ab:NAME=V    same-box A/B of a library option: cfg2 / chunk_l1 / cfg3 with and without --opt NAME=V, twice, interleaved
+#   abprev       same-box A/B against an earlier commit's tree built under .ab/prev
+#   skew         profiles/microbench/units_skew.hip (uneven H shares per XCD: even / weighted launches alternate)
 #   traces       rocprofv3 --kernel-trace --stats of the named workloads
 #   pmc          rocprofv3 --pmc passes (cfg2 with the source hash, cfg3)
 #   power        power / clock traces
@@ -115,6 +117,15 @@ PY
   ab) for rep in 1 2; do for W in ${ABW:-cfg2 chunk_l1 cfg3}; do
         b ${W}_base_$rep --workload $W --no-cpu-baseline --no-extras
         b ${W}_${ARG%%=*}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"
+      done; done;;
+  abprev) # same-box A/B of the tree against a copy of an earlier commit built under .ab/prev (git archive REV bench.py distributedmandelbrot_amd include oracle)
+      for rep in 1 2; do for W in ${ABW:-cfg2 chunk_l1}; do
+        timeout 900 python .ab/prev/bench.py --workload $W --no-cpu-baseline --no-extras > "$OUT/bench_${W}_prev_$rep.log" 2>&1; line "$OUT/bench_${W}_prev_$rep.log"
+        b ${W}_now_$rep --workload $W --no-cpu-baseline --no-extras
+        python - "$OUT/bench_${W}_now_$rep.log" <<'PY'
+import json,sys
+r=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); print("     xcd_shares", r["config"].get("xcd_shares"))
+PY
       done; done;;
   traces) for W in ${ARG:-cfg2 chunk_l1 cfg3 exterior}; do
         case $W in cfg3) X="--steps 10 --warmup 2";; cfg4) X="--steps 2 --warmup 1";; *) X="";; esac
