@@ -448,7 +448,8 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         const double est = (double)grid.x * (share + (1.0 - share) / 8.0);
         const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
         uint32_t g = (uint32_t)std::min<double>((double)grid.x, est * 1.15 + 2048.0);
-        g = (std::max(g, std::min(grid.x, cus * 64u)) + 7u) & ~7u;   // a multiple of 8: id mod 8 = workgroup mod 8 = the XCD
+        // a multiple of 8: id mod 8 = workgroup mod 8 = the XCD; at least 2^14: bounds a wave's trips (the kernel's packed statistics)
+        g = (std::max(std::max(g, std::min(grid.x, cus * 64u)), 16384u) + 7u) & ~7u;
         a.unit_stride = g;
         uint32_t qtab = 0u;   // quantised bytes of counts 1..4, packed (the light path's table)
         if (a.bytes && a.mrd > 0)

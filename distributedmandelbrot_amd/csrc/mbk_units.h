@@ -205,8 +205,12 @@ template <typename T, int kGroup, bool kCycle, bool kCounts, bool kBytes, bool k
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void tile_units_kernel(TileArgs args, uint32_t qtab)
 {
     static_assert(!kStats || (!kCounts && kBytes), "fused statistics exist for the bytes-only instantiation");
-    unsigned long long heavy_iters = 0;     // pixel-iterations / never-escaped pixels of the blocks computed by block_pixel
-    uint32_t heavy_never = 0, acc = 0;      // acc: counts of the blocks the light path finished (<= 4 each)
+    // Statistics of the blocks computed by block_pixel, per lane, in ONE 64-bit register (this instantiation has no vector
+    // register to spare at 8 waves per SIMD): pixel-iterations in bits 0..46, never-escaped pixels above.  A wave computes at
+    // most 8 blocks per trip and makes at most 2^13 trips (grid.x < 2^27 regions, the stride at least 2^14 ids): fewer than
+    // 2^16 blocks, under 2^31 iterations each.
+    unsigned long long heavy = 0;
+    uint32_t acc = 0;                       // counts of the blocks the light path finished (<= 4 each)
     const uint32_t never_cap = args.mrd > 1 ? (uint32_t)args.mrd - 1u : 0u;
     // The loop keeps the launch's arguments alive across a whole block, and the escape loops need their share of the 96
     // scalar registers that 8 waves per SIMD leave a wave.  What this kernel never uses is pinned to the value the host
@@ -244,10 +248,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const uint32_t by = e >> 16, bx = e & 0xffffu;
             const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h,
                                                                    bx < p.fast_bx_end && by < p.fast_by_end);
-            if (kStats && c >= 0) {
-                heavy_iters += c > 0 ? (uint32_t)c : never_cap;
-                heavy_never += c == 0 ? 1u : 0u;
-            }
+            if (kStats && c >= 0) heavy += c > 0 ? (unsigned long long)(uint32_t)c : (1ull << 47) + never_cap;
         } else {
             const uint32_t v = scalar_load_u32(p.order, n - 1u - (i - n_m));
             const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
@@ -263,17 +264,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             while (escape_light_row<kCounts, kBytes, kStats>(ci, b0, col, p.re.step, p.re.start, cnt, cb, bb, off, 8u * oscale, qtab, mask, k, &acc) != 0u) {
                 // block k of the unit outlives the light path (the probe saw only its centre pixel): the whole block, exactly
                 const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, (bx0 + k) * 8u, by * 8u, lx, ly, false, true);
-                if (kStats && c >= 0) {
-                    heavy_iters += c > 0 ? (uint32_t)c : never_cap;
-                    heavy_never += c == 0 ? 1u : 0u;
-                }
+                if (kStats && c >= 0) heavy += c > 0 ? (unsigned long long)(uint32_t)c : (1ull << 47) + never_cap;
                 if (++k >= 8u) break;
             }
         }
     }
     if (kStats) {
         // (acc cannot wrap: <= 4 per block, and a wave handles far fewer than 2^29 blocks)
-        const unsigned long long iters = wave_sum_u64(heavy_iters + acc), never = wave_sum_u64((unsigned long long)heavy_never);
+        const unsigned long long iters = wave_sum_u64((heavy & ((1ull << 47) - 1ull)) + acc), never = wave_sum_u64(heavy >> 47);
         ReduceOut *out = &args.stats[blockIdx.x % kReduceSlots].r;
         if (lane == 0) {
             if (iters) atomicAdd(&out->pixel_iterations, iters);
