@@ -27,6 +27,7 @@
 constexpr uint32_t kTail = 8;   // stamps per XCD
 
 struct Plan {
+    uint32_t rot;       // diagnostic: XCD x takes the list positions of XCD (x + rot) mod 8 in the evenly dealt part
     uint32_t h[8];      // H units of XCD x
     uint32_t l[8];      // light units (M, then V) of XCD x
     uint32_t hmin, lmin, n_h, n_m, n_v, slots;   // slots: workgroup ids per XCD
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (b < 8u && lane == 0) { stamps[b] = t0; xcc_of[b] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u; }
     const uint32_t hx = pl.h[x];
     if (j < hx) {
-        const uint32_t i = j < pl.hmin ? 8u * j + x : rank8(pl.h, j, x);
+        const uint32_t i = j < pl.hmin ? 8u * j + ((x + pl.rot) & 7u) : rank8(pl.h, j, x);
         const uint32_t e = mbk::uniform_u32(p.order[i]);
         const uint32_t by = e >> 16, bx = e & 0xffffu;
         mbk::block_pixel<double, true, 16, false>(p, bx * 8u, by * 8u, lx, ly, true, bx < p.fast_bx_end && by < p.fast_by_end);
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     const uint32_t k = j - hx;
     if (k >= pl.l[x]) return;
-    const uint32_t i = k < pl.lmin ? 8u * k + x : rank8(pl.l, k, x);
+    const uint32_t i = k < pl.lmin ? 8u * k + ((x + pl.rot) & 7u) : rank8(pl.l, k, x);
     if (i < pl.n_m) {
         const uint32_t e = mbk::uniform_u32(p.order[n + 3u + i]);
         const uint32_t by = e >> 16, bx = e & 0xffffu;
@@ -121,6 +122,7 @@ int main(int argc, char **argv)
     const std::string wl = argc > 1 ? argv[1] : "cfg2";
     const int reps = argc > 2 ? atoi(argv[2]) : 40;
     const double gain = argc > 3 ? atof(argv[3]) : 0.5;
+    const uint32_t rot = argc > 4 ? (uint32_t)atoi(argv[4]) : 0u;
     const uint32_t W = 4096, H = 4096, mrd = 1000;
     mbk::TileArgs a; memset(&a, 0, sizeof(a));
     auto mk = [](double start, double range, uint32_t n) { mbk::Axis x; memset(&x, 0, sizeof(x)); x.start = start; x.n = n;
@@ -146,7 +148,7 @@ int main(int argc, char **argv)
     mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks);
     CHECK(hipMemcpy(cnt, ord + nblocks, 12, hipMemcpyDeviceToHost));
     const uint32_t n_h = cnt[0], n_v = cnt[1], n_m = cnt[2];
-    printf("%s: H %u, V units %u, M %u; controller gain %.2f\n", wl.c_str(), n_h, n_v, n_m, gain);
+    printf("%s: H %u, V units %u, M %u; controller gain %.2f, rotation %u\n", wl.c_str(), n_h, n_v, n_m, gain, rot);
 
     double f[8], even[8];
     for (int x = 0; x < 8; ++x) f[x] = even[x] = 0.125;
@@ -154,7 +156,8 @@ int main(int argc, char **argv)
     std::vector<int32_t> href((size_t)W * H), hnow((size_t)W * H);
     for (int rep = 0; rep < reps + 4; ++rep) {
         const bool weighted = rep >= 4 && (rep & 1);      // four even launches to warm up, then alternate
-        const Plan pl = make_plan(weighted ? f : even, n_h, n_m, n_v);
+        Plan pl = make_plan(weighted ? f : even, n_h, n_m, n_v);
+        pl.rot = rot;
         memset(stamps, 0, (8 + 8 * kTail) * 8);
         if (rep == reps + 3 || rep == reps + 2) CHECK(hipMemset(a.counts, 0xff, (size_t)W * H * 4));
         CHECK(hipDeviceSynchronize());

@@ -8,6 +8,7 @@
 #   issue        profiles/microbench/valu_issue.hip (fp64 issue rate in shader cycles)
 #   clock[:W:K ...]  the shader clock (s_memtime / s_memrealtime, a one-wave probe in a second process) while bench.py runs workload W for K steps
 #   headline     bench.py as the driver runs it
+#   balance      MBK_OPT_XCD_BALANCE on / off on the same box (queue job, cfg2, DataChunk (1,0,0))
 #   n2           the N > 1 paths with two ranks on this box's one GPU (--oversubscribe; functional)
 #   emulate      scripts/scale_emulate.py -> scale_prediction.json
 #   benches      the other bench lines (kernels, workloads)
@@ -50,6 +51,14 @@ print("     t(ms):MHz:probe ms  " + "  ".join(f"{t:.0f}:{m:.0f}:{d:.2f}" for t,m
 PY
       done;;
   headline) b cfg2_default;;
+  balance) # MBK_OPT_XCD_BALANCE on (default) / off, same box: the queue job (4 tiles in flight) and the own-mode legs of cfg2 and DataChunk (1,0,0)
+      for rep in 1 2; do
+        b queue_n1_balance_$rep --shard queue --no-cpu-baseline
+        b queue_n1_even_$rep --shard queue --no-cpu-baseline --opt xcd_balance=0
+        for W in cfg2 chunk_l1; do
+          b ${W}_balance_$rep --workload $W --no-cpu-baseline --no-extras
+          b ${W}_even_$rep --workload $W --no-cpu-baseline --no-extras --opt xcd_balance=0
+        done; done;;
   n2) b queue_n1 --shard queue --no-cpu-baseline
       b queue_n2_oversub --gpus 2 --oversubscribe
       b bands_n2_oversub --gpus 2 --oversubscribe --shard bands --workload cfg3 --steps 6
@@ -101,7 +110,7 @@ PY
         cat "$OUT/units_trace_$W.txt"; rm -f "$OUT/units_trace_$W.bin"
       done;;
   skew) [ -x build/units_skew ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip 2> "$OUT/build_units_skew.log"
-      for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.25}; do
+      for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.25}; do   # workload,launches,gain[,rotation]
         timeout 120 build/units_skew ${A//,/ } > "$OUT/units_skew_${A//,/_}.txt" 2>&1; tail -4 "$OUT/units_skew_${A//,/_}.txt"
       done;;
   events) for rep in 1 2; do for W in cfg2 chunk_l1; do
@@ -135,6 +144,7 @@ PY
        pmcrun cfg2_a "$C1" --steps 20 --warmup 5; pmcrun cfg2_b "$C2" --steps 20 --warmup 5
        pmcrun cfg2_w "WRITE_SIZE" --steps 20 --warmup 5; pmcrun cfg2_f "FETCH_SIZE" --steps 20 --warmup 5
        python scripts/pmc_summary.py "$OUT/cfg2_default_pmc_by_kernel.json" "$OUT/pmc_cfg2_a" "$OUT/pmc_cfg2_b" "$OUT/pmc_cfg2_w" "$OUT/pmc_cfg2_f" --match tile_
+       [ "$ARG" = cfg2 ] && ARG=" "   # pmc:cfg2 = the headline workload only
        for W in ${ARG:-cfg3 chunk_l1}; do
          case $W in cfg3) X="--steps 4 --warmup 1";; *) X="--steps 20 --warmup 5";; esac
          pmcrun ${W}_a "$C1" --workload $W $X; pmcrun ${W}_b "$C2" --workload $W $X
