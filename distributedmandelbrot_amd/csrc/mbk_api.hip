@@ -61,7 +61,7 @@ struct StreamScratch {
     unsigned long long *h_stamps = nullptr;
     double xcd_f[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
     uint32_t xcd_issued = 0, xcd_consumed = 0;
-    struct SharesUsed { uint32_t seq; float f[8]; } xcd_ring[64] = {};
+    struct SharesUsed { uint32_t seq, switches; float f[8]; } xcd_ring[64] = {};   // switches: the ctx' stream_switches at the launch
 };
 static const size_t kMaxStreamScratch = 64;
 static const uint32_t kStampSlots = 16, kShareRing = 64;
@@ -92,6 +92,8 @@ struct mbk_ctx {
     uint8_t *d_rle = nullptr;        // RLE scratch: block counts | run starts | run values | output stream
     size_t rle_cap_px = 0;
     uint32_t opt[MBK_OPT_COUNT_];    // tuning options (mbk_set_option); every value is bit-exact
+    hipStream_t last_tile_stream = nullptr;   // launch_tile: the stream of the last tile launch, and how often it changed
+    uint32_t stream_switches = 0;             // (xcd_shares_update: which launches had the chip to themselves)
     int scan_occ[2][2] = {{0, 0}, {0, 0}};  // resident single-wave workgroups per CU: [f64|f32][scan|heavy]
     int scan_occ_inline[2] = {0, 0};        // the same for pass 1 in its finish-in-place form (MBK_OPT_SCAN_INLINE)
     uint32_t wave_limit_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MBK_OPT_WAVE_LIMIT: dynamic LDS bytes per single-wave workgroup
@@ -276,9 +278,13 @@ static double window_heavy_share(const TileArgs &a);
 // Kernel "units": new H fractions for the eight XCDs from the time stamps of the launches on this stream that have finished
 // since the last look (mbk_units.h).  A launch that dealt XCD x the fraction f_x of the H list and saw it deal its last
 // ids T_x after the launch's first workgroup started measures its speed as f_x / T_x; the fractions follow the normalised
-// speeds with a gain of 1/2, clamped to +-12 % of an even deal.  A slot whose 72 stamps do not all carry the launch's
-// number (still running, overwritten, a grid too small to reach the tail on the first trip) is skipped.
-static void xcd_shares_update(StreamScratch &sc)
+// speeds with a gain of 0.3, clamped to +-12 % of an even deal.  A slot whose 72 stamps do not all carry the launch's
+// number (still running, overwritten, a grid too small to reach the tail on the first trip) is skipped -- and so is every
+// launch that did not have the chip to itself as far as this ctx can tell: with several streams in flight an XCD's stamps
+// say when it found room for this launch among the others, not how fast it is (measured: the fractions then drift the
+// wrong way, profiles/r04/xcd_balance_ab.txt), so a launch counts only if no tile launch of the ctx went to another stream
+// between the units launch before it and the one after it.
+static void xcd_shares_update(const mbk_ctx *ctx, StreamScratch &sc)
 {
     const unsigned long long kMask = 0xffffffffffffull;
     uint32_t first = sc.xcd_issued >= kStampSlots ? sc.xcd_issued - kStampSlots + 1u : 1u;
@@ -287,6 +293,9 @@ static void xcd_shares_update(StreamScratch &sc)
         const volatile unsigned long long *st = sc.h_stamps + (size_t)(c % kStampSlots) * mbk::kStampWords;
         const StreamScratch::SharesUsed &used = sc.xcd_ring[c % kShareRing];
         if (used.seq != c) continue;
+        const StreamScratch::SharesUsed &before = sc.xcd_ring[(c - 1u) % kShareRing], &after = sc.xcd_ring[(c + 1u) % kShareRing];
+        const bool alone = c > 1u && before.seq == c - 1u && before.switches == used.switches &&
+                           (c == sc.xcd_issued ? ctx->stream_switches == used.switches : after.seq == c + 1u && after.switches == used.switches);
         unsigned long long v[mbk::kStampWords];
         bool whole = true;
         for (uint32_t i = 0; i < mbk::kStampWords; ++i) {
@@ -307,14 +316,14 @@ static void xcd_shares_update(StreamScratch &sc)
             tmax = std::max(tmax, T[x]);
         }
         sc.xcd_consumed = c;
-        if (tmin < 1000.0 || tmax > 1.25 * tmin) continue;   // under 10 us, or nothing a share could explain
+        if (!alone || tmin < 1000.0 || tmax > 1.25 * tmin) continue;   // under 10 us, or nothing a share could explain
         for (uint32_t x = 0; x < 8u; ++x) {
             speed[x] = (double)used.f[x] / T[x];
             sum += speed[x];
         }
         double fs = 0.0;
         for (uint32_t x = 0; x < 8u; ++x) {
-            const double f = 0.5 * sc.xcd_f[x] + 0.5 * speed[x] / sum;
+            const double f = 0.7 * sc.xcd_f[x] + 0.3 * speed[x] / sum;
             sc.xcd_f[x] = std::min(0.14, std::max(0.11, f));
             fs += sc.xcd_f[x];
         }
@@ -409,12 +418,13 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                                            hipHostMallocDefault));
                 std::memset(sc->h_stamps, 0xff, (size_t)kStampSlots * mbk::kStampWords * sizeof(unsigned long long));
             }
-            if (balance == 1u) xcd_shares_update(*sc);
+            if (balance == 1u) xcd_shares_update(ctx, *sc);
             mbk::XcdShares w;
             double f[8];
             const uint32_t seq = ++sc->xcd_issued;
             StreamScratch::SharesUsed &used = sc->xcd_ring[seq % kShareRing];
             used.seq = seq;
+            used.switches = ctx->stream_switches;
             for (uint32_t x = 0; x < 8u; ++x) {
                 f[x] = balance == 1u ? sc->xcd_f[x] : (balance == 2u ? kUneven[x] : 0.125);
                 used.f[x] = (float)f[x];
@@ -789,6 +799,10 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
                        ReduceSlot *fuse = nullptr, bool counts_unwanted = false, bool *fused = nullptr)
 {
     if (fused) *fused = false;
+    if (stream != ctx->last_tile_stream) {
+        ctx->last_tile_stream = stream;
+        ++ctx->stream_switches;
+    }
     bool safe = false;
     const bool f32 = (flags & MBK_PRECISION_F32) != 0;
     int rc = validate_view(ctx, v, &safe, f32);
