@@ -411,7 +411,9 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                                (int32_t)probe_steps, ord, cursors);
             // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
             // stream, 2 a fixed uneven deal (tests)
-            const uint32_t balance = ctx->opt[MBK_OPT_XCD_BALANCE];
+            // (1 applies to the strict loops only: with the cycle test a launch ends with the drain of its boundary blocks, which
+            // the stamps -- when an XCD dealt its last ids -- do not see; following them cost 0.3 % there, xcd_balance_ab.txt)
+            const uint32_t balance = ctx->opt[MBK_OPT_XCD_BALANCE] == 1u && cyc ? 0u : ctx->opt[MBK_OPT_XCD_BALANCE];
             static const double kUneven[8] = {0.110, 0.140, 0.125, 0.120, 0.130, 0.125, 0.115, 0.135};
             if (balance == 1u && !sc->h_stamps) {
                 MBK_HIP(ctx, hipHostMalloc((void **)&sc->h_stamps, (size_t)kStampSlots * mbk::kStampWords * sizeof(unsigned long long),

@@ -282,8 +282,10 @@ enum mbk_option {
     MBK_OPT_XCD_BALANCE,   /* order 3: shares of the eight XCDs in the units kernel's list of heavy blocks.  The XCDs of one chip run
                               2-10 % apart and the hardware deals them equal numbers of workgroups, so a launch lasts as long as
                               its slowest XCD: 0 even shares, [1] shares that follow the time stamps earlier launches on the same
-                              stream left in pinned memory (72 stores per launch; the first launch on a stream is even), 2 a fixed
-                              uneven deal (tests).  Changes when a block is computed, never what is stored */
+                              stream left in pinned memory (72 stores per launch; the first launch on a stream is even; only
+                              launches without the cycle test, and only those that had the chip to themselves, are followed:
+                              strict cfg2 +0.7..1.2 %), 2 a fixed uneven deal (tests).  Changes when a block is computed, never
+                              what is stored */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
