@@ -495,6 +495,43 @@ def test_units_order_every_output_set_and_shape(oracle):
                             assert np.array_equal(db.cpu().numpy().reshape(nrows, ncols), ob), tag
 
 
+def test_xcd_shares_follow_solitary_strict_launches():
+    """MBK_OPT_XCD_BALANCE = 1 (csrc/mbk_units.h, mbk_api.hip: xcd_shares_update): launches without the cycle test that have the
+    chip to themselves leave 72 time stamps in pinned memory, and the host reads them at the next launch -- the feedback loop is
+    alive (stamps arrive whole and carry the launch number), the shares stay a distribution inside their clamp, and the
+    counts are what they were under the even deal; launches WITH the cycle test neither leave stamps nor move the shares."""
+    import torch
+    from distributedmandelbrot_amd import MandelbrotDevice
+    view, mrd = View(-2.0, -1.5, 3.0, 3.0, 4096, 4096), 1000
+    d = torch.zeros(4096 * 4096, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    with MandelbrotDevice(0) as dev:
+        dev.set_option("cycle_detect", 0)
+        dev.set_option("xcd_balance", 0)
+        dev.launch_view(view, mrd, d_counts=d.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        even = d.clone()
+        base = dev.xcd_shares()
+        assert base["last_launch_read"] == 0 and base["shares"] == [0.125] * 8
+        dev.set_option("xcd_balance", 1)
+        for _ in range(12):
+            d.fill_(-5)
+            dev.launch_view(view, mrd, d_counts=d.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            assert torch.equal(d, even)
+        s = dev.xcd_shares()
+        assert s["units_launches"] == base["units_launches"] + 12
+        assert s["last_launch_read"] >= s["units_launches"] - 2, s      # every launch but the newest has been read
+        assert abs(sum(s["shares"]) - 1.0) < 1e-3 and all(0.105 < f < 0.145 for f in s["shares"]), s
+        dev.set_option("cycle_detect", 1)
+        for _ in range(4):
+            dev.launch_view(view, mrd, d_counts=d.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+        assert torch.equal(d, even)
+        s2 = dev.xcd_shares()
+        assert s2["shares"] == s["shares"] and s2["last_launch_read"] == s["last_launch_read"], (s, s2)
+
+
 def test_quantiser_every_count_on_device(gpu, oracle):
     """The device divides by multiplying with a host reciprocal (mbk_kernels.h: quantise); check it
     against the reference's float form (WorkerCUDA.py:96-98, restated by the oracle) for EVERY count of
