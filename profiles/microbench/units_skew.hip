@@ -11,7 +11,9 @@
 // the controller takes a speed estimate (share / time) from every launch.
 // Same device code as the product (classify_units_kernel, block_pixel, escape_light_row from csrc/).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip
-//   build/units_skew cfg2 40
+//   build/units_skew cfg2 40 [gain 0.5] [rotation 0] [cycle test 0|1] [signal 0 = dry stamps | 1 = end of the XCD's last wave]
+// (signal 1 is a diagnostic -- every workgroup stores its end time, the host takes the maximum per XCD -- for the question the
+// product left open: with the cycle test a launch ends with the drain of its boundary blocks, which the dry stamps do not see.)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -44,8 +46,10 @@ __device__ __forceinline__ uint32_t rank8(const uint32_t *c, uint32_t j, uint32_
     return r;
 }
 
+template <bool kCycle>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void skew_units_kernel(mbk::TileArgs args, uint32_t qtab, Plan pl,
-                                                                                                 unsigned long long *stamps, uint32_t *xcc_of)
+                                                                                                 unsigned long long *stamps, uint32_t *xcc_of,
+                                                                                                 unsigned long long *ends)
 {
     const unsigned long long t0 = wall_clock64();
     mbk::TileArgs p = args;
@@ -60,16 +64,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const uint32_t i = j < pl.hmin ? 8u * j + ((x + pl.rot) & 7u) : rank8(pl.h, j, x);
         const uint32_t e = mbk::uniform_u32(p.order[i]);
         const uint32_t by = e >> 16, bx = e & 0xffffu;
-        mbk::block_pixel<double, true, 16, false>(p, bx * 8u, by * 8u, lx, ly, true, bx < p.fast_bx_end && by < p.fast_by_end);
+        mbk::block_pixel<double, true, 16, kCycle>(p, bx * 8u, by * 8u, lx, ly, true, bx < p.fast_bx_end && by < p.fast_by_end);
+        if (lane == 0) ends[b] = wall_clock64();
         return;
     }
     const uint32_t k = j - hx;
-    if (k >= pl.l[x]) return;
+    if (k >= pl.l[x]) { if (lane == 0) ends[b] = 0ull; return; }
     const uint32_t i = k < pl.lmin ? 8u * k + ((x + pl.rot) & 7u) : rank8(pl.l, k, x);
     if (i < pl.n_m) {
         const uint32_t e = mbk::uniform_u32(p.order[n + 3u + i]);
         const uint32_t by = e >> 16, bx = e & 0xffffu;
-        mbk::block_pixel<double, true, 16, false>(p, bx * 8u, by * 8u, lx, ly, false, bx < p.fast_bx_end && by < p.fast_by_end);
+        mbk::block_pixel<double, true, 16, kCycle>(p, bx * 8u, by * 8u, lx, ly, false, bx < p.fast_bx_end && by < p.fast_by_end);
     } else {
         const uint32_t v = mbk::uniform_u32(p.order[n - 1u - (i - pl.n_m)]);
         const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
@@ -80,10 +85,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         uint32_t kk = 0;
         int32_t cnt;
         while (mbk::escape_light_row<true, false>(ci, b0, col, p.re.step, p.re.start, cnt, cb, nullptr, off, 32u, qtab, mask, kk) != 0u) {
-            mbk::block_pixel<double, true, 16, false>(p, (bx0 + kk) * 8u, by * 8u, lx, ly, false, true);
+            mbk::block_pixel<double, true, 16, kCycle>(p, (bx0 + kk) * 8u, by * 8u, lx, ly, false, true);
             if (++kk >= 8u) break;
         }
     }
+    if (lane == 0) ends[b] = wall_clock64();
 }
 
 // the shares of a launch from the fractions f (sum 1): h by cumulative rounding, light = what is left of S ids per XCD
@@ -123,6 +129,8 @@ int main(int argc, char **argv)
     const int reps = argc > 2 ? atoi(argv[2]) : 40;
     const double gain = argc > 3 ? atof(argv[3]) : 0.5;
     const uint32_t rot = argc > 4 ? (uint32_t)atoi(argv[4]) : 0u;
+    const bool cyc = argc > 5 && atoi(argv[5]) != 0;
+    const int signal = argc > 6 ? atoi(argv[6]) : 0;
     const uint32_t W = 4096, H = 4096, mrd = 1000;
     mbk::TileArgs a; memset(&a, 0, sizeof(a));
     auto mk = [](double start, double range, uint32_t n) { mbk::Axis x; memset(&x, 0, sizeof(x)); x.start = start; x.n = n;
@@ -141,6 +149,8 @@ int main(int argc, char **argv)
     uint32_t *ord; CHECK(hipMalloc(&ord, (2 * (size_t)nblocks + 3) * 4));
     a.order = ord; a.ngrid = nblocks; a.unit_stride = nblocks;
     unsigned long long *stamps; CHECK(hipHostMalloc(&stamps, (8 + 8 * kTail) * 8, hipHostMallocDefault));
+    unsigned long long *ends; CHECK(hipMalloc(&ends, (size_t)nblocks * 8));
+    std::vector<unsigned long long> hends(nblocks);
     uint32_t *xcc_of; CHECK(hipHostMalloc(&xcc_of, 8 * 4, hipHostMallocDefault));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     uint32_t cnt[3] = {0, 0, 0};
@@ -148,7 +158,17 @@ int main(int argc, char **argv)
     mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks);
     CHECK(hipMemcpy(cnt, ord + nblocks, 12, hipMemcpyDeviceToHost));
     const uint32_t n_h = cnt[0], n_v = cnt[1], n_m = cnt[2];
-    printf("%s: H %u, V units %u, M %u; controller gain %.2f, rotation %u\n", wl.c_str(), n_h, n_v, n_m, gain, rot);
+    printf("%s: H %u, V units %u, M %u; controller gain %.2f, rotation %u, cycle test %d, signal %s\n", wl.c_str(), n_h, n_v, n_m, gain, rot, (int)cyc,
+           signal ? "end of the last wave per XCD" : "dry stamps");
+    {   // the clock ramps for the first ~100 launches after an idle period: get that out of the way
+        const double ev[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
+        const Plan pw = make_plan(ev, n_h, n_m, n_v);
+        for (int w = 0; w < 150; ++w) {
+            if (cyc) skew_units_kernel<true><<<pw.slots * 8, 64>>>(a, 0u, pw, stamps, xcc_of, ends);
+            else skew_units_kernel<false><<<pw.slots * 8, 64>>>(a, 0u, pw, stamps, xcc_of, ends);
+        }
+        CHECK(hipDeviceSynchronize());
+    }
 
     double f[8], even[8];
     for (int x = 0; x < 8; ++x) f[x] = even[x] = 0.125;
@@ -162,7 +182,8 @@ int main(int argc, char **argv)
         if (rep == reps + 3 || rep == reps + 2) CHECK(hipMemset(a.counts, 0xff, (size_t)W * H * 4));
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
-        skew_units_kernel<<<pl.slots * 8, 64>>>(a, 0u, pl, stamps, xcc_of);
+        if (cyc) skew_units_kernel<true><<<pl.slots * 8, 64>>>(a, 0u, pl, stamps, xcc_of, ends);
+        else skew_units_kernel<false><<<pl.slots * 8, 64>>>(a, 0u, pl, stamps, xcc_of, ends);
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -174,8 +195,16 @@ int main(int argc, char **argv)
             for (uint32_t t = 0; t < kTail; ++t) last = std::max(last, stamps[8 + x * kTail + t]);
             T[x] = (double)(last - start) / 100.0;   // us
         }
+        // the other signal: when the last wave of every XCD ended
+        double E[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        CHECK(hipMemcpy(hends.data(), ends, (size_t)pl.slots * 8 * 8, hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < pl.slots * 8; ++b)
+            if (hends[b] > start) E[b & 7] = std::max(E[b & 7], (double)(hends[b] - start) / 100.0);
         printf("%s rep %2d %s %.4f ms  ids/XCD %u  dry at us:", wl.c_str(), rep, weighted ? "W" : "E", ms, pl.slots);
         for (int x = 0; x < 8; ++x) printf(" %6.1f", T[x]);
+        printf("  ended at:");
+        for (int x = 0; x < 8; ++x) printf(" %6.1f", E[x]);
+        if (signal) for (int x = 0; x < 8; ++x) T[x] = E[x];
         printf("  h:");
         for (int x = 0; x < 8; ++x) printf(" %u", pl.h[x]);
         printf("\n");

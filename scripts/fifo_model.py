@@ -36,6 +36,8 @@ ap.add_argument("--start-ns", type=float, default=700.0)
 ap.add_argument("--end-ns", type=float, default=300.0)
 ap.add_argument("--slots", type=int, default=8)
 ap.add_argument("--light-k", type=int, default=0, help="also model light workgroups that take K list entries each")
+ap.add_argument("--cycle", action="store_true", help="the library's default: the cycle test retires periodic orbits (oracle.view_cycle: executed steps per pixel)")
+ap.add_argument("--study", default="orders", choices=["orders", "tail"], help="tail: which class should be dispatched first (end of round 4)")
 ap.add_argument("--sub", type=int, default=8, help="simulate 1024 / SUB SIMDs with every SUB-th workgroup of the order (dispatcher slowed by SUB)")
 args = ap.parse_args()
 
@@ -49,6 +51,10 @@ B = c.reshape(nb, 8, nb, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
 center = c[4::8, 4::8].reshape(-1)
 heavy = (center == 0) | (center >= 32)            # classify_blocks_kernel: centre pixel alive after 32 steps
 last = np.minimum(np.where(B == 0, 10 ** 9, B).max(1), T)
+if args.cycle:
+    # a lane leaves at its escape step or when the cycle test retires it; the wave runs until its last lane has left
+    ex = o.view_cycle(*view, N, N, args.mrd, first=8, check=8)[1]
+    last = np.minimum(ex.reshape(nb, 8, nb, 8).transpose(0, 2, 1, 3).reshape(-1, 64).max(1), T)
 instr = last * 6.2 + 40.0
 NS = 1024 // args.sub
 NS_PER_INSTR = args.cpi / args.clock              # ns of one SIMD per wave-instruction
@@ -176,6 +182,66 @@ def report(name, order_instr):
 
 idx = np.arange(len(B))
 h, l = idx[heavy], idx[~heavy][::-1]
+if args.study == "tail":
+    # The units order as built (H = centre alive at 32 steps, M = centre gone at step 4..31, V = gone within 3 steps, eight to a
+    # workgroup) against orders that send the straggler-prone blocks out earlier.  Motivation (profiles/r04/units_skew_cycle.txt):
+    # with the cycle test every XCD's last wave ends 15-25 us (6-8 % of the launch) after its dispatcher ran dry -- boundary
+    # blocks of class M, dispatched behind all of H, that run (nearly) all mrd - 1 steps, while the interior (H) retires early.
+    vl = (~heavy) & (center >= 1) & (center <= 3)
+    mid = (~heavy) & ~vl
+
+    def runs_of(sel, k=8):
+        li = np.where(last[idx[sel]] <= 4, 18.5, instr[idx[sel]] + 20.0)
+        pad = (-len(li)) % k
+        return np.concatenate([li, np.zeros(pad)]).reshape(-1, k).sum(1) + 40.0
+
+    vruns = runs_of(vl)
+    report("units as built: H, M, V runs", np.concatenate([instr[h], instr[idx[mid]], vruns]))
+    report("M first, then H, then V runs", np.concatenate([instr[idx[mid]], instr[h], vruns]))
+    # a richer probe: centre + four corners of the block, 32 steps; alive anywhere -> long
+    probes = [c[4::8, 4::8], c[0::8, 0::8], c[0::8, 7::8], c[7::8, 0::8], c[7::8, 7::8]]
+    alive5 = np.zeros(len(B), bool)
+    for pr in probes:
+        pr = pr.reshape(-1)
+        alive5 |= (pr == 0) | (pr >= 32)
+    m_long = mid & alive5
+    print(f"classes: H {int(heavy.sum())}, M {int(mid.sum())} of which a corner is alive at 32 steps {int(m_long.sum())}, V blocks {int(vl.sum())} "
+          f"(V blocks with a live corner: {int((vl & alive5).sum())})")
+    report("H, M with a live corner, other M, V runs", np.concatenate([instr[h], instr[idx[m_long]], instr[idx[mid & ~m_long]], vruns]))
+    report("M with a live corner, H, other M, V runs", np.concatenate([instr[idx[m_long]], instr[h], instr[idx[mid & ~m_long]], vruns]))
+    # the bound: every single-block workgroup in order of its true cost (not realisable: needs the answer)
+    singles = np.concatenate([instr[h], instr[idx[mid]]])
+    report("all single blocks longest first (oracle order), V runs", np.concatenate([np.sort(singles)[::-1], vruns]))
+    # M by the centre probe's escape step, latest first (what classify knows already)
+    order_m = idx[mid][np.argsort(-center[idx[mid]], kind="stable")]
+    report("H, M by centre escape step (latest first), V runs", np.concatenate([instr[h], instr[order_m], vruns]))
+    report("M by centre escape step (latest first), H, V runs", np.concatenate([instr[order_m], instr[h], vruns]))
+    # What the probe already knows at no extra cost: how fast the centre pixel's orbit is settling after its 32 steps,
+    # delta = min over p in {1..6, 8} of |z_32 - z_(32-p)|^2.  With the cycle test an interior block whose orbit has settled
+    # retires within a few checks, one near the boundary runs (nearly) all steps: H blocks with a large delta first.
+    re = np.linspace(view[0], view[0] + view[2], N)[4::8]
+    im = np.linspace(view[1], view[1] + view[3], N)[4::8]
+    CR, CI = np.meshgrid(re, im)
+    pcr, pci = CR.reshape(-1)[h], CI.reshape(-1)[h]
+    zr, zi, hist = pcr.copy(), pci.copy(), {}
+    with np.errstate(all="ignore"):
+        for n in range(1, 33):
+            zr, zi = zr * zr - zi * zi + pcr, 2 * zr * zi + pci
+            if n >= 24:
+                hist[n] = (zr.copy(), zi.copy())
+        delta = np.full(len(h), np.inf)
+        for p_ in (1, 2, 3, 4, 5, 6, 8):
+            delta = np.minimum(delta, (hist[32][0] - hist[32 - p_][0]) ** 2 + (hist[32][1] - hist[32 - p_][1]) ** 2)
+    delta = np.where(np.isfinite(delta), delta, 1e30)
+    for thr in (1e-9, 1e-6, 1e-4):
+        slow = delta > thr
+        report(f"H unsettled (delta > {thr:g}: {int(slow.sum())}) first, settled H, M, V runs",
+               np.concatenate([instr[h][slow], instr[h][~slow], instr[idx[mid]], vruns]))
+    b3 = np.digitize(np.log10(delta + 1e-300), [-9.0, -6.0, -4.0])      # 0 settled .. 3 far from it
+    report("H in four delta classes, least settled first, M, V runs",
+           np.concatenate([instr[h][b3 == 3], instr[h][b3 == 2], instr[h][b3 == 1], instr[h][b3 == 0], instr[idx[mid]], vruns]))
+    report("H sorted by delta (largest first), M, V runs", np.concatenate([instr[h][np.argsort(-delta, kind="stable")], instr[idx[mid]], vruns]))
+    sys.exit(0)
 inset = last[h] >= T
 report("image order", instr)
 report("heavy first (what the kernels do)", np.concatenate([instr[h], instr[l]]))

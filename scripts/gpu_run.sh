@@ -110,7 +110,7 @@ PY
         cat "$OUT/units_trace_$W.txt"; rm -f "$OUT/units_trace_$W.bin"
       done;;
   skew) [ -x build/units_skew ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip 2> "$OUT/build_units_skew.log"
-      for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.25}; do   # workload,launches,gain[,rotation]
+      for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.5,0,1,0 cfg2,40,0.5,0,1,1}; do   # workload,launches,gain[,rotation[,cycle test[,signal]]]
         timeout 120 build/units_skew ${A//,/ } > "$OUT/units_skew_${A//,/_}.txt" 2>&1; tail -4 "$OUT/units_skew_${A//,/_}.txt"
       done;;
   events) for rep in 1 2; do for W in cfg2 chunk_l1; do
