@@ -407,14 +407,22 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
         if (units) {
+            // MBK_OPT_H_SETTLED = k > 0: H blocks whose probe orbit is within 10^-k of settled are dispatched behind the others
+            const uint32_t hs = ctx->opt[MBK_OPT_H_SETTLED];
+            const double settle_thr = hs ? std::pow(10.0, -(double)hs) : 0.0;
+            MBK_HIP(ctx, hipMemsetAsync(ord + 2u * (size_t)grid.x + 3u, 0, sizeof(uint32_t), pre));   // count of settled H entries
             hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a, grid.x,
-                               (int32_t)probe_steps, ord, cursors);
+                               (int32_t)probe_steps, ord, cursors, settle_thr);
             // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
             // stream, 2 a fixed uneven deal (tests)
             // (1 applies to the strict loops only: with the cycle test a launch ends with the drain of its boundary blocks, which
             // the stamps -- when an XCD dealt its last ids -- do not see; following them cost 0.3 % there, xcd_balance_ab.txt)
             const uint32_t balance = ctx->opt[MBK_OPT_XCD_BALANCE] == 1u && cyc ? 0u : ctx->opt[MBK_OPT_XCD_BALANCE];
             static const double kUneven[8] = {0.110, 0.140, 0.125, 0.120, 0.130, 0.125, 0.115, 0.135};
+            // 3: a fixed prior, no feedback and no stamps -- the even XCDs 1.6 % more than the odd ones (the odd XCDs ran 1.8 %
+            // behind their even neighbours on every box of rounds 4-5: profiles/NOTES.md 2b); applies to every launch, whatever
+            // else is in flight
+            static const double kPrior[8] = {0.126, 0.124, 0.126, 0.124, 0.126, 0.124, 0.126, 0.124};
             if (balance == 1u && !sc->h_stamps) {
                 MBK_HIP(ctx, hipHostMalloc((void **)&sc->h_stamps, (size_t)kStampSlots * mbk::kStampWords * sizeof(unsigned long long),
                                            hipHostMallocDefault));
@@ -428,15 +436,15 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             used.seq = seq;
             used.switches = ctx->stream_switches;
             for (uint32_t x = 0; x < 8u; ++x) {
-                f[x] = balance == 1u ? sc->xcd_f[x] : (balance == 2u ? kUneven[x] : 0.125);
+                f[x] = balance == 1u ? sc->xcd_f[x] : (balance == 2u ? kUneven[x] : (balance == 3u ? kPrior[x] : 0.125));
                 used.f[x] = (float)f[x];
             }
             shares_from_fractions(f, w.cum);
             a.plan = ord + ((2u * (size_t)grid.x + 3u + 15u) & ~(size_t)15u);
             a.stamps = balance == 1u ? sc->h_stamps + (size_t)(seq % kStampSlots) * mbk::kStampWords : nullptr;
             a.stamp_tag = seq & 0xffffu;
-            hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)cursors, w, a.stamps ? 1u : 0u,
-                               (uint32_t *)a.plan);
+            hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)cursors,
+                               (const uint32_t *)(ord + 2u * (size_t)grid.x + 3u), w, a.stamps ? 1u : 0u, (uint32_t *)a.plan);
         } else
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a,
                            grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
@@ -1003,7 +1011,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 1u};
+        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 1u, /* H_SETTLED */ 0u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1443,7 +1451,8 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;
         case MBK_OPT_UNITS_MIN_LIGHT: ok = value <= 65536u; break;
-        case MBK_OPT_XCD_BALANCE: ok = value <= 2u; break;
+        case MBK_OPT_XCD_BALANCE: ok = value <= 3u; break;
+        case MBK_OPT_H_SETTLED: ok = value <= 30u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

@@ -284,8 +284,13 @@ enum mbk_option {
                               its slowest XCD: 0 even shares, [1] shares that follow the time stamps earlier launches on the same
                               stream left in pinned memory (72 stores per launch; the first launch on a stream is even; only
                               launches without the cycle test, and only those that had the chip to themselves, are followed:
-                              strict cfg2 +0.7..1.2 %), 2 a fixed uneven deal (tests).  Changes when a block is computed, never
+                              strict cfg2 +0.7..1.2 %), 2 a fixed uneven deal (tests), 3 a fixed prior without stamps or feedback
+                              (even XCDs 0.126, odd 0.124), applied to every launch.  Changes when a block is computed, never
                               what is stored */
+    MBK_OPT_H_SETTLED,     /* order 3: [0] one list of heavy blocks; k = 1..30: heavy blocks whose probe orbit is within 10^-k of settled
+                              (min over p of |z_last - z_(last-p)|^2 of the centre pixel) are dispatched behind the others -- with
+                              the cycle test those retire within a few checks while the unsettled ones run (nearly) all steps
+                              (profiles/NOTES.md 2c).  Changes when a block is computed, never what is stored */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

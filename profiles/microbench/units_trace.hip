@@ -85,7 +85,7 @@ int main(int argc, char **argv)
     uint32_t cnt[3] = {0, 0, 0};
     for (int rep = 0; rep < 4; ++rep) {
         CHECK(hipMemset(ord + nblocks, 0, 12));
-        mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks);
+        mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, 0.0);
         CHECK(hipMemcpy(cnt, ord + nblocks, 12, hipMemcpyDeviceToHost));
         const uint32_t total = cnt[0] + cnt[1] + cnt[2];
         CHECK(hipMemset(d, 0, (size_t)nblocks * sizeof(Rec)));

@@ -109,6 +109,18 @@ PY
         timeout 600 python scripts/analyze_units_trace.py "$OUT/units_trace_$W.bin" >> "$OUT/units_trace_$W.txt" 2>&1
         cat "$OUT/units_trace_$W.txt"; rm -f "$OUT/units_trace_$W.bin"
       done;;
+  fill) hipcc --offload-arch=gfx950 -O3 -o /tmp/fill profiles/microbench/fill.hip 2> "$OUT/build_fill.log" && timeout 300 /tmp/fill > "$OUT/fill.txt" 2>&1; cat "$OUT/fill.txt"
+      b exterior_fillbox --workload exterior --no-cpu-baseline --no-extras; b exterior_both_fillbox --workload exterior --outputs both --no-cpu-baseline --no-extras;;
+  pmccyc) # PMC of the default kernel WITH the cycle test (the library default), with and without an option: pmccyc:NAME=V[:workloads]
+      O=${ARG%%:*}; WL=${ARG#*:}; [ "$WL" = "$ARG" ] && WL="cfg2 chunk_l1"
+      C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+      C2="SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+      for W in $WL; do X="--steps 20 --warmup 5"
+        for V in base opt; do [ $V = opt ] && OO="--opt $O" || OO=""
+          pmcrun ${W}_cyc_${V}_a "$C1" --workload $W $X $OO --opt cycle_detect=1; pmcrun ${W}_cyc_${V}_b "$C2" --workload $W $X $OO --opt cycle_detect=1
+          python scripts/pmc_summary.py "$OUT/${W}_cyc_${V}_pmc_by_kernel.json" "$OUT/pmc_${W}_cyc_${V}_a" "$OUT/pmc_${W}_cyc_${V}_b" --match tile_ | cut -c1-600
+        done; done
+      rm -rf "$OUT"/pmc_*_?;;
   skew) [ -x build/units_skew ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip 2> "$OUT/build_units_skew.log"
       for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.5,0,1,0 cfg2,40,0.5,0,1,1}; do   # workload,launches,gain[,rotation[,cycle test[,signal]]]
         timeout 120 build/units_skew ${A//,/ } > "$OUT/units_skew_${A//,/_}.txt" 2>&1; tail -4 "$OUT/units_skew_${A//,/_}.txt"
@@ -125,7 +137,7 @@ PY
       done;;
   ab) for rep in 1 2; do for W in ${ABW:-cfg2 chunk_l1 cfg3}; do
         b ${W}_base_$rep --workload $W --no-cpu-baseline --no-extras
-        b ${W}_${ARG%%=*}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"
+        b ${W}_${ARG//=/}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"
       done; done;;
   abprev) # same-box A/B of the tree against a copy of an earlier commit built under .ab/prev (git archive REV bench.py distributedmandelbrot_amd include oracle)
       for rep in 1 2; do for W in ${ABW:-cfg2 chunk_l1}; do

@@ -413,6 +413,9 @@ OPTION_MATRIX = [
     ("group", {"order": 2}), ("group", {"order": 3, "group_steps": 8}), ("group", {"order": 3, "waves_per_wg": 2}),
     ("group", {"order": 3, "xcd_balance": 0}), ("group", {"order": 3, "xcd_balance": 2, "units_min_light": 0}),
     ("default", {"xcd_balance": 2, "cycle_detect": 0}),
+    ("group", {"order": 3, "h_settled": 6}), ("group", {"order": 3, "h_settled": 6, "cycle_detect": 0, "xcd_balance": 2, "units_min_light": 0}),
+    ("default", {"h_settled": 1}), ("group", {"order": 3, "h_settled": 30, "units_min_light": 0}),
+    ("default", {"xcd_balance": 3}), ("group", {"order": 3, "xcd_balance": 3, "h_settled": 5, "cycle_detect": 0}),
 ]
 
 
