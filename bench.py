@@ -308,8 +308,9 @@ def end_to_end(dev, level=16, mrd=1024):
     """the tile rate INCLUDING quantise + statistics + D2H, reported beside the headline.  A whole
     level of the reference's pyramid (level n = n x n DataChunk tiles of [-2,2]^2, Distributer.cs:335-353 hands out
     every one of them) through the host-buffer API into pinned memory, library defaults (cycle test on):
-    synchronous (WorkerCUDA.py:87-98's shape), two tiles in flight, and two in flight with uniform tiles not
-    copied off the GPU (MBK_LAZY_UNIFORM: what worker.run_pipelined does)."""
+    synchronous (WorkerCUDA.py:87-98's shape), two tiles in flight (rounds 1-4's pipeline) and MBK_SLOTS (4) in flight, each
+    also with MBK_LAZY_UNIFORM (what worker.run_pipelined / mbk_worker_run do: uniform tiles are not copied off the GPU and
+    tiles wholly outside |c| = 2 cost no GPU work)."""
     import numpy as np
     tiles = [(ir, ii) for ir in range(level) for ii in range(level)]
     n = len(tiles)
@@ -326,17 +327,22 @@ def end_to_end(dev, level=16, mrd=1024):
         iters += st.pixel_iterations
     t_sync = time.perf_counter() - t0
 
-    def two_slots(lazy):
+    def in_flight(k, lazy):
+        """the whole level with k tiles in flight: submit tile i on slot i % k, retire the oldest when all k are taken"""
         t1 = time.perf_counter()
-        dev.submit_datachunk(0, level, mrd, *tiles[0], pins[0], lazy_uniform=lazy)
-        for i in range(1, n + 1):
+        for i in range(n + k):
+            if i >= k:
+                dev.wait((i - k) % k)
             if i < n:
-                dev.submit_datachunk(i % 2, level, mrd, *tiles[i], pins[i % 2], lazy_uniform=lazy)
-            dev.wait((i - 1) % 2)
+                dev.submit_datachunk(i % k, level, mrd, *tiles[i], pins[i % k], lazy_uniform=lazy)
         return time.perf_counter() - t1
 
-    t_two = two_slots(False)
-    t_lazy = two_slots(True)
+    nslots = int(getattr(dev, "SLOTS", 2))
+    pins += [dev.pinned_empty((16777216,), np.uint8) for _ in range(nslots - len(pins))]
+    t_two = in_flight(2, False)
+    t_lazy = in_flight(2, True)
+    t_all = in_flight(nslots, False)
+    t_all_lazy = in_flight(nslots, True)
     ks_sorted = sorted(ks)
     return {"what": f"level {level} of the reference's pyramid, mrd {mrd}: {n} DataChunk tiles (4096^2) through the host-buffer "
                     "API on one context -- kernel + quantise + statistics + D2H of the 16 MiB byte tile into pinned memory, "
@@ -344,6 +350,9 @@ def end_to_end(dev, level=16, mrd=1024):
             "tiles": n, "uniform_never_tiles": int(never), "uniform_immediate_tiles": int(imm),
             "tiles_per_s_synchronous": n / t_sync, "tiles_per_s_two_in_flight": n / t_two,
             "tiles_per_s_two_in_flight_lazy_uniform": n / t_lazy,
+            "slots": nslots, "tiles_per_s_all_slots_in_flight": n / t_all, "tiles_per_s_all_slots_in_flight_lazy_uniform": n / t_all_lazy,
+            "lazy_uniform": "MBK_LAZY_UNIFORM, what the worker loops use: a tile wholly outside |c| = 2 is answered on the host "
+                            "(no GPU work: every count is 1), a uniform tile is not copied off the GPU",
             "G_pixel_iterations_per_s_wall_synchronous": iters / t_sync / 1e9,
             "kernel_ms_median": ks_sorted[n // 2], "kernel_ms_mean": sum(ks) / n, "kernel_ms_max": ks_sorted[-1],
             "d2h_ms_mean": sum(ds) / n}

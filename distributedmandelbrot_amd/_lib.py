@@ -28,11 +28,13 @@ KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MB
 # enum mbk_option (include/mbk.h), in order
 OPTIONS = {name: i for i, name in enumerate(
     ["order", "waves_per_wg", "group_steps", "exact_steps", "probe_steps", "scan_waves", "scan_xcd_map", "scan_col_period", "heavy_share",
-     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid", "prepass_overlap", "exact_long", "scan_inline", "wave_limit", "units_min_light", "xcd_balance", "h_settled"])}
+     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid", "prepass_overlap", "exact_long", "scan_inline", "wave_limit", "units_min_light", "xcd_balance", "m_late"])}
 MBK_PRECISION_F32 = 0x1000
 MBK_LAZY_UNIFORM = 0x2000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
-MBK_SLOTS = 2
+MBK_SLOTS = 4
+MBK_INFO_SCAN_WG_PER_CU = 100
+MBK_INFO_XCD_SHARE = 110
 MBK_CODEC_RAW = 0x00
 MBK_CODEC_RLE = 0x01
 MBK_CHUNK_DEFINITION = 4096
@@ -69,7 +71,7 @@ class mbk_worker_report(C.Structure):
 
 # enum mbk_net_option (include/mbk.h), in order: process-wide network behaviour of the native worker loop
 NET_OPTIONS = {name: i for i, name in enumerate(
-    ["max_connections", "connect_timeout_ms", "io_timeout_ms", "retries", "backoff_ms", "stop", "peak_connections"])}
+    ["max_connections", "connect_timeout_ms", "io_timeout_ms", "retries", "backoff_ms", "stop", "peak_connections", "feeder_slots"])}
 
 
 FEEDER_SUBMIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
@@ -98,6 +100,7 @@ SIGNATURES = {
     "mbk_datachunk_geometry": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]),
+    "mbk_view_outside_circle": (C.c_int, [C.POINTER(mbk_view), C.c_uint32, C.POINTER(C.c_int)]),
     "mbk_view_launch": (C.c_int, [C.c_void_p, C.POINTER(mbk_view), C.c_uint32, C.c_uint32,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "mbk_view_compute": (C.c_int, [C.c_void_p, C.POINTER(mbk_view), C.c_uint32, C.c_uint32,

@@ -78,8 +78,10 @@ struct Slot {
     ReduceSlot *h_red = nullptr;  // pinned copy of d_red
     bool busy = false;           // submitted, not yet waited for
     bool with_bytes = false;
-    uint8_t *lazy_h_bytes = nullptr;  // MBK_LAZY_UNIFORM: the byte copy is decided in mbk_wait
+    uint8_t *lazy_h_bytes = nullptr;  // MBK_LAZY_UNIFORM without a copy enqueued at submit: the byte copy is decided in mbk_wait
     size_t lazy_px = 0;
+    bool immediate = false;      // MBK_LAZY_UNIFORM, window wholly outside |c| = 2: nothing was enqueued, `imm` is the result
+    mbk_stats imm = {};
 };
 
 struct mbk_ctx {
@@ -407,22 +409,19 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
         if (units) {
-            // MBK_OPT_H_SETTLED = k > 0: H blocks whose probe orbit is within 10^-k of settled are dispatched behind the others
-            const uint32_t hs = ctx->opt[MBK_OPT_H_SETTLED];
-            const double settle_thr = hs ? std::pow(10.0, -(double)hs) : 0.0;
-            MBK_HIP(ctx, hipMemsetAsync(ord + 2u * (size_t)grid.x + 3u, 0, sizeof(uint32_t), pre));   // count of settled H entries
+            // MBK_OPT_M_LATE = s > 0: M blocks whose centre pixel escapes at step >= s open the dispatch order (mbk_units.h)
+            MBK_HIP(ctx, hipMemsetAsync(ord + 2u * (size_t)grid.x + 3u, 0, sizeof(uint32_t), pre));   // count of late M entries
             hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a, grid.x,
-                               (int32_t)probe_steps, ord, cursors, settle_thr);
+                               (int32_t)probe_steps, ord, cursors, (int32_t)ctx->opt[MBK_OPT_M_LATE]);
             // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
             // stream, 2 a fixed uneven deal (tests)
             // (1 applies to the strict loops only: with the cycle test a launch ends with the drain of its boundary blocks, which
             // the stamps -- when an XCD dealt its last ids -- do not see; following them cost 0.3 % there, xcd_balance_ab.txt)
-            const uint32_t balance = ctx->opt[MBK_OPT_XCD_BALANCE] == 1u && cyc ? 0u : ctx->opt[MBK_OPT_XCD_BALANCE];
+            // (and to a whole chip only: the stamps' "workgroup id mod 8 = XCD" is the dispatch order of 8 XCDs x 32 CUs -- a
+            // partitioned device, CPX / DPX modes, deals differently: ADVICE r4)
+            const uint32_t balance = ctx->opt[MBK_OPT_XCD_BALANCE] == 1u && (cyc || ctx->prop.multiProcessorCount != 256)
+                                         ? 0u : ctx->opt[MBK_OPT_XCD_BALANCE];
             static const double kUneven[8] = {0.110, 0.140, 0.125, 0.120, 0.130, 0.125, 0.115, 0.135};
-            // 3: a fixed prior, no feedback and no stamps -- the even XCDs 1.6 % more than the odd ones (the odd XCDs ran 1.8 %
-            // behind their even neighbours on every box of rounds 4-5: profiles/NOTES.md 2b); applies to every launch, whatever
-            // else is in flight
-            static const double kPrior[8] = {0.126, 0.124, 0.126, 0.124, 0.126, 0.124, 0.126, 0.124};
             if (balance == 1u && !sc->h_stamps) {
                 MBK_HIP(ctx, hipHostMalloc((void **)&sc->h_stamps, (size_t)kStampSlots * mbk::kStampWords * sizeof(unsigned long long),
                                            hipHostMallocDefault));
@@ -436,7 +435,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             used.seq = seq;
             used.switches = ctx->stream_switches;
             for (uint32_t x = 0; x < 8u; ++x) {
-                f[x] = balance == 1u ? sc->xcd_f[x] : (balance == 2u ? kUneven[x] : (balance == 3u ? kPrior[x] : 0.125));
+                f[x] = balance == 1u ? sc->xcd_f[x] : (balance == 2u ? kUneven[x] : 0.125);
                 used.f[x] = (float)f[x];
             }
             shares_from_fractions(f, w.cum);
@@ -1011,7 +1010,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 1u, /* H_SETTLED */ 0u};
+        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1181,6 +1180,37 @@ int mbk_view_launch(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, uint32_t f
     return launch_tile(ctx, view, mrd, flags, d_counts, d_bytes, (hipStream_t)hip_stream);
 }
 
+// The window's TileArgs as far as the host-side tests need them (axes + window)
+static TileArgs view_window_args(const mbk_view *v)
+{
+    TileArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.re = make_axis(v->start_r, v->range_r, v->width);
+    a.im = make_axis(v->start_i, v->range_i, v->height);
+    a.col0 = v->col0;
+    a.row0 = v->row0;
+    a.ncols = v->ncols;
+    a.nrows = v->nrows;
+    return a;
+}
+
+// Does every sample of the window lie outside the circle |c| = 2, with room to spare: |c|^2 >= 4 (1 + m), m = 1e-8
+// (fp64) / 1e-4 (fp32)?  The samples of an axis lie between its two end samples up to a few units in the last place
+// (k * step + start is monotonic in k before rounding), which the margin covers 10^7 times over.
+static bool view_outside_circle2(const mbk_view *v, bool f32)
+{
+    const TileArgs a = view_window_args(v);
+    const double x0 = axis_value_host(a.re, a.col0), x1 = axis_value_host(a.re, a.col0 + a.ncols - 1u);
+    const double y0 = axis_value_host(a.im, a.row0), y1 = axis_value_host(a.im, a.row0 + a.nrows - 1u);
+    const double xlo = std::fmin(x0, x1), xhi = std::fmax(x0, x1), ylo = std::fmin(y0, y1), yhi = std::fmax(y0, y1);
+    const double dx = (xlo <= 0.0 && 0.0 <= xhi) ? 0.0 : std::fmin(std::fabs(xlo), std::fabs(xhi));
+    const double dy = (ylo <= 0.0 && 0.0 <= yhi) ? 0.0 : std::fmin(std::fabs(ylo), std::fabs(yhi));
+    const double rmin2 = dx * dx + dy * dy;
+    return rmin2 >= 4.0 * (1.0 + (f32 ? 1e-4 : 1e-8));
+}
+
+static double view_probe_share(const mbk_view *v) { return window_heavy_share(view_window_args(v)); }
+
 // enqueue kernel + reduction + D2H of one tile on a slot's stream (no host synchronisation)
 static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mrd, uint32_t flags,
                        int32_t *h_counts, uint8_t *h_bytes)
@@ -1193,6 +1223,27 @@ static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mr
     int rc = validate_view(ctx, view, &dummy, (flags & MBK_PRECISION_F32) != 0);
     if (rc != MBK_OK) return rc;
     const size_t px = (size_t)view->ncols * view->nrows;
+    const bool lazy = wb && (flags & MBK_LAZY_UNIFORM) != 0;
+    const bool f32 = (flags & MBK_PRECISION_F32) != 0;
+    sl.immediate = false;
+    if (lazy && !wc && mrd >= 256u && mrd <= 0x7fffffffu && view_outside_circle2(view, f32)) {
+        // Every pixel of the window has |c| >= 2 (1 + 1e-8): the reference's first update z1 = c^2 + c has
+        // |z1| = |c| |c + 1| >= |c| (|c| - 1) > 2, so calc_mb_value returns 1 for each of them (WorkerCUDA.py:54-63; the proof
+        // with the rounding errors of the five operations: tests/test_oracle.py::test_outside_circle_escapes_at_step_one)
+        // and the quantised byte is ceil(256 / mrd) = 1 for mrd >= 256: DataChunk.cs:87's "Immediate" chunk.  With
+        // MBK_LAZY_UNIFORM such a tile is not copied anyway, so nothing is enqueued at all: the corners of [-2, 2]^2 outside
+        // the inscribed circle, 1 - pi/4 = 21 % of the tiles of a deep pyramid level (32 of level 16's 256).
+        std::memset(&sl.imm, 0, sizeof(sl.imm));
+        sl.imm.pixel_iterations = (uint64_t)px;
+        sl.imm.all_bytes_one = 1u;
+        sl.imm.rle_runs = 1ull;
+        sl.immediate = true;
+        sl.lazy_h_bytes = nullptr;
+        sl.busy = true;
+        sl.with_bytes = true;
+        if (&sl == &ctx->s[0]) ctx->last_px = 0;   // (no bytes on the device: mbk_serialize_last has nothing to read)
+        return MBK_OK;
+    }
     rc = ensure_buffers(ctx, sl, px);
     if (rc != MBK_OK) return rc;
     // counts are always produced on the device (they feed the stats reduction); only what the
@@ -1211,11 +1262,18 @@ static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mr
     rc = launch_reduce(ctx, sl, fused ? nullptr : sl.d_counts, wb ? sl.d_bytes : nullptr, px, mrd, sl.stream, false);
     if (rc != MBK_OK) return rc;
     MBK_HIP(ctx, hipEventRecord(sl.ev_c0, sl.stream));
-    const bool lazy = wb && (flags & MBK_LAZY_UNIFORM) != 0;
-    if (wb && !lazy) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, sl.d_bytes, px, hipMemcpyDeviceToHost, sl.stream));
+    // MBK_LAZY_UNIFORM: whether the tile is uniform is known only when its statistics are -- deciding the copy then costs a
+    // synchronisation, an enqueue and a second synchronisation per tile (round 4: 20 % of a pyramid level's wall time).  So
+    // the copy is enqueued NOW unless the host's 16 x 16 probe of the window says "every pixel gone within 4 steps" (the
+    // all-exterior tile: counts 1..4, byte 1 everywhere for mrd >= 1024); a uniform tile that was copied anyway (an all-interior one)
+    // wasted 0.3 ms of the copy engine beside its own 2 ms kernel, a non-uniform one that was not takes the old path in
+    // mbk_wait.  Either way the caller is told by the stats whether h_bytes matters.
+    bool lazy_deferred = false;
+    if (lazy) lazy_deferred = view_probe_share(view) == 0.0;
+    if (wb && !lazy_deferred) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, sl.d_bytes, px, hipMemcpyDeviceToHost, sl.stream));
     if (wc) MBK_HIP(ctx, hipMemcpyAsync(h_counts, sl.d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost, sl.stream));
     MBK_HIP(ctx, hipEventRecord(sl.ev_c1, sl.stream));
-    sl.lazy_h_bytes = lazy ? h_bytes : nullptr;
+    sl.lazy_h_bytes = lazy_deferred ? h_bytes : nullptr;
     sl.lazy_px = px;
     sl.busy = true;
     sl.with_bytes = wb;
@@ -1226,6 +1284,12 @@ static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mr
 static int wait_slot(mbk_ctx *ctx, Slot &sl, mbk_stats *stats)
 {
     if (!sl.busy) return fail(ctx, MBK_ERR_INVALID, "nothing was submitted on this slot");
+    if (sl.immediate) {   // decided on the host at submit: nothing is in flight
+        sl.busy = false;
+        sl.immediate = false;
+        if (stats) *stats = sl.imm;
+        return MBK_OK;
+    }
     MBK_HIP(ctx, hipStreamSynchronize(sl.stream));
     sl.busy = false;
     if (sl.lazy_h_bytes) {   // MBK_LAZY_UNIFORM: copy the bytes only if the tile is not all-0 / all-1
@@ -1302,6 +1366,17 @@ int mbk_view_submit(mbk_ctx *ctx, int slot, const mbk_view *view, uint32_t mrd, 
     if (slot < 0 || slot >= MBK_SLOTS) return fail(ctx, MBK_ERR_INVALID, "slot out of range");
     MBK_HIP(ctx, hipSetDevice(ctx->device));
     return submit_view(ctx, ctx->s[slot], view, mrd, flags, h_counts, h_bytes);
+}
+
+int mbk_view_outside_circle(const mbk_view *view, uint32_t flags, int *outside)
+{
+    if (!view || !outside) return fail(nullptr, MBK_ERR_INVALID, "NULL argument");
+    bool dummy;
+    const bool f32 = (flags & MBK_PRECISION_F32) != 0;
+    const int rc = validate_view(nullptr, view, &dummy, f32);
+    if (rc != MBK_OK) return rc;
+    *outside = view_outside_circle2(view, f32) ? 1 : 0;
+    return MBK_OK;
 }
 
 int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats)
@@ -1451,8 +1526,8 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;
         case MBK_OPT_UNITS_MIN_LIGHT: ok = value <= 65536u; break;
-        case MBK_OPT_XCD_BALANCE: ok = value <= 3u; break;
-        case MBK_OPT_H_SETTLED: ok = value <= 30u; break;
+        case MBK_OPT_XCD_BALANCE: ok = value <= 2u; break;
+        case MBK_OPT_M_LATE: ok = value <= 65536u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");
@@ -1599,6 +1674,10 @@ int mbk_net_set_option(int option, uint32_t value)
             c.backoff_ms.store(value);
             return MBK_OK;
         case MBK_NET_STOP: c.stop.store(value ? 1u : 0u); return MBK_OK;
+        case MBK_NET_FEEDER_SLOTS:
+            if (value < 1u || value > 8u) return fail(nullptr, MBK_ERR_INVALID, "feeder slots must be in 1..8");
+            c.feeder_slots.store(value);
+            return MBK_OK;
         default: return fail(nullptr, MBK_ERR_INVALID, "unknown MBK_NET_* selector");
     }
 }
@@ -1614,6 +1693,7 @@ int mbk_net_get_option(int option, uint32_t *value)
         case MBK_NET_RETRIES: *value = c.retries.load(); return MBK_OK;
         case MBK_NET_BACKOFF_MS: *value = c.backoff_ms.load(); return MBK_OK;
         case MBK_NET_STOP: *value = c.stop.load(); return MBK_OK;
+        case MBK_NET_FEEDER_SLOTS: *value = c.feeder_slots.load(); return MBK_OK;
         case MBK_NET_PEAK_CONNECTIONS: {
             std::lock_guard<std::mutex> g(c.m);
             *value = c.peak;
@@ -1629,7 +1709,7 @@ int mbk_feeder_run(const mbk_feeder_ops *ops, const char *addr, uint16_t port, u
     if (!ops || !ops->submit || !ops->wait || !ops->alloc || !ops->release || !addr)
         return fail(nullptr, MBK_ERR_INVALID, "NULL argument");
     std::string err;
-    const int rc = mbkf::run(ops, addr, port, max_tiles, senders, report, &err);
+    const int rc = mbkf::run(ops, addr, port, max_tiles, senders, report, &err, mbkf::net().feeder_slots.load());
     if (rc != MBK_OK) return fail(nullptr, rc, err);
     return MBK_OK;
 }
@@ -1649,7 +1729,7 @@ int mbk_worker_run(mbk_ctx *ctx, const char *addr, uint16_t port, uint64_t max_t
     ops.release = ctx_release;
     ops.on_tile = nullptr;
     std::string err;
-    const int rc = mbkf::run(&ops, addr, port, max_tiles, senders, report, &err);
+    const int rc = mbkf::run(&ops, addr, port, max_tiles, senders, report, &err, (uint32_t)MBK_SLOTS);
     if (rc != MBK_OK) {
         // a backend failure left its own message on the ctx; keep it, prefixed
         const std::string inner = ctx->err;

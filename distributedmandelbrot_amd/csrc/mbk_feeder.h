@@ -8,8 +8,9 @@
 // the reference's; only the timing of the two exchanges of DIFFERENT tiles overlaps (any connection may return any
 // leased tile), exactly like distributedmandelbrot_amd/worker.py: run_pipelined, whose structure this
 // is:
-//     this thread    lease tile n+1 | backend: tile n on slot n % 2 (its D2H overlaps the kernel of the other slot)
-//     sender threads tile n-1 ... on their own connections; `senders + 2` result buffers circulate, so a slow server
+//     this thread    lease tile n+1 | backend: tile n on slot n % k (its D2H overlaps the kernels of the other slots; k = 4
+//                    for mbk_worker_run, MBK_NET_FEEDER_SLOTS for mbk_feeder_run)
+//     sender threads tile n-1 ... on their own connections; `senders + k` result buffers circulate, so a slow server
 //                    back-pressures the lease rate instead of growing a queue
 // Tiles the backend reports as uniform (all 0 = "Never", all 1 = "Immediate": DataChunk.cs:82,87) were not copied
 // off the GPU (MBK_LAZY_UNIFORM); their 16 MiB payload is one of two shared constant buffers.
@@ -98,6 +99,7 @@ struct NetConfig {
     std::atomic<uint32_t> retries{6};               // attempts after the first, per exchange
     std::atomic<uint32_t> backoff_ms{50};           // first pause; doubles per attempt, capped at 2 s, + jitter
     std::atomic<uint32_t> stop{0};
+    std::atomic<uint32_t> feeder_slots{2};          // mbk_feeder_run: tiles on the backend at once
     std::mutex m;
     std::condition_variable cv;
     uint32_t open = 0;                              // connections open or being opened, all feeders of the process
@@ -257,8 +259,9 @@ static bool recv_exact(int fd, uint8_t *p, size_t n, int *e)
 }
 
 // First connection of W.py:115-134.  1 = a workload, 0 = 0x11 (none available), -1 = error.  Transient failures are
-// retried with backoff (a lease the server registered for a connection that then broke is lost to everybody for its
-// hour -- Distributer.cs:22 -- but a refused / reset connect never reached the hand-out code).
+// retried with backoff while the hand-out code cannot have run: a refused / reset / timed-out CONNECT, a failed send, a
+// close or reset before the reply byte.  A reply that times out after the request was sent is NOT retried (a lease the
+// server registered for a reply nobody read is lost to everybody for its hour -- Distributer.cs:22).
 static int lease(const char *addr, uint16_t port, uint32_t w[4], std::string *err, uint64_t *retried)
 {
     const uint32_t attempts = 1u + net().retries.load();
@@ -276,9 +279,16 @@ static int lease(const char *addr, uint16_t port, uint32_t w[4], std::string *er
                 again = transient_errno(e) && e != 0;
             } else {
                 uint8_t op = kRequest, reply = 0, raw[16];
-                if (!send_all(fd, &op, 1, nullptr, &e) || !recv_exact(fd, &reply, 1, &e)) {
+                if (!send_all(fd, &op, 1, nullptr, &e)) {
                     *err = errno_text("workload request", e);
                     again = transient_errno(e);
+                } else if (!recv_exact(fd, &reply, 1, &e)) {
+                    // The request is out.  An orderly close or a reset before the reply byte never reached the hand-out
+                    // code: ask again.  A TIMEOUT is different: the server registers the lease as it sends 0x10 + the
+                    // workload (Distributer.cs HandleWorkloadRequest), so a reply that was sent but not read in time
+                    // would orphan that tile for its hour and the retry would take a second one: an error.
+                    *err = errno_text("workload request (no reply)", e);
+                    again = e == 0 || e == ECONNRESET || e == ECONNABORTED || e == EPIPE;
                 } else if (reply == kNotAvailable) {
                     rc = 0;
                 } else if (reply != kAvailable) {
@@ -354,13 +364,15 @@ static int give_back(const char *addr, uint16_t port, const uint32_t w[4], const
 }
 
 // The loop.  `ops` is the compute backend (mbk_worker_run binds it to a GPU context).
+// nslots: tiles on the backend at once (slot numbers 0 .. nslots-1, in turn)
 static int run(const mbk_feeder_ops *ops, const char *addr, uint16_t port, uint64_t max_tiles, uint32_t senders,
-               mbk_worker_report *rep, std::string *err)
+               mbk_worker_report *rep, std::string *err, uint32_t nslots = 2)
 {
     if (senders == 0) senders = 1;
     if (senders > 64) senders = 64;
+    nslots = std::min<uint32_t>(std::max<uint32_t>(nslots, 1u), 8u);
     const auto t0 = std::chrono::steady_clock::now();
-    const uint32_t nbuf = senders + 2;
+    const uint32_t nbuf = senders + nslots;
     std::vector<uint8_t *> bufs;
     for (uint32_t k = 0; k < nbuf; ++k) {
         uint8_t *b = (uint8_t *)ops->alloc(ops->user, kChunkBytes);
@@ -415,11 +427,16 @@ static int run(const mbk_feeder_ops *ops, const char *addr, uint16_t port, uint6
     std::vector<std::thread> threads;
     for (uint32_t k = 0; k < senders; ++k) threads.emplace_back(sender);
 
-    Tile *inflight[2] = {nullptr, nullptr};
+    Tile *inflight[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int rc = MBK_OK;
     bool more = true;
     int slot = 0;
-    while (more || inflight[0] || inflight[1]) {
+    auto any_inflight = [&]() {
+        for (uint32_t k = 0; k < nslots; ++k)
+            if (inflight[k]) return true;
+        return false;
+    };
+    while (more || any_inflight()) {
         uint32_t w[4];
         bool have = false;
         {
@@ -481,7 +498,7 @@ static int run(const mbk_feeder_ops *ops, const char *addr, uint16_t port, uint6
                 inflight[slot] = t;
             }
         }
-        slot ^= 1;
+        slot = (slot + 1) % (int)nslots;
     }
     for (size_t k = 0; k < threads.size(); ++k) outbox.put(nullptr);
     for (std::thread &t : threads) t.join();

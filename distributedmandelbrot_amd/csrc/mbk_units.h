@@ -37,47 +37,26 @@ namespace mbk {
 // the back, order[n .. n+3) the counters (H, V units, M), order[n+3 .. 2n+3) the M entries.  H / M entry: (block row << 16)
 // | block column.  V unit: (block row << 16) | (first block column / 8) << 8 | mask of the V blocks among its 8 columns.
 // Needs blocks_x % 8 == 0 (a unit never wraps a row), blocks_x <= 2048, block rows < 65536 (the host checks).
-// With settle_thr > 0 the settled H entries sit at the back of the M region (order[2n+2] downwards, count at order[2n+3]).
-// The probe of classify_units_kernel: the reference loop for the centre pixel, `cap` - 1 updates at most (escape_count), and
-// for a pixel that is still inside at the end how far its orbit is from settled: delta = min over p in {1..6, 8} of
-// |z_last - z_(last-p)|^2.  With the cycle test an interior block whose orbit has settled on its attracting cycle retires
-// within a few checks, one whose orbit has not runs (nearly) all mrd - 1 steps (cfg2: delta > 1e-6 selects 42 % of the H
-// blocks, which hold 98.5 % of those that run >= 900 steps: profiles/NOTES.md 2c).  A scheduling hint: any arithmetic will do.
-__device__ __forceinline__ int32_t probe_settling(double cr, double ci, int32_t cap, double *delta)
-{
-    double zr = cr, zi = ci, sr[7], si[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) sr[k] = si[k] = 1e300;
-    for (int32_t n = 1; n < cap; ++n) {
-        const double t = zr * zr - zi * zi;
-        zi = __builtin_fma(2.0, zr * zi, ci);
-        zr = t + cr;
-        if (zr * zr + zi * zi >= 4.0) { *delta = 1e300; return n; }
-        const int32_t back = cap - 1 - n;        // this state is z_(last - back)
-#pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (back == (k < 6 ? k + 1 : 8)) { sr[k] = zr; si[k] = zi; }
-    }
-    double d = 1e300;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const double dr = zr - sr[k], di = zi - si[k], q = dr * dr + di * di;
-        d = q < d ? q : d;
-    }
-    *delta = d;
-    return 0;
-}
-
-// settle_thr > 0: H entries whose probe orbit is within settle_thr of settled ("H0") are filed from the BACK of the M
-// region (order[2n+2], order[2n+1], ...; their count at order[2n+3]) and dispatched behind the unsettled ones; 0: one H list.
+// With m_late > 0 the "late" M entries sit at the back of the M region (order[2n+2] downwards, count at order[2n+3]).
+//
+// M LATE (round 5).  A block with a pixel that never escapes runs all mrd - 1 steps, and from its start to its end it needs
+// >= 6 125 dependent-issue instructions ~ 21 us however empty the chip is (a lone wave issues one fp64 instruction per ~8
+// cycles: profiles/r04/valu_issue.txt).  The H class is dispatched first, so its long blocks have the whole launch to finish;
+// but ~200 blocks of the M class (centre gone within 32 steps, a corner of the block inside the set: cfg2 209 of 47 805,
+// DataChunk (1,0,0) 175 of 26 812) run just as long and were dispatched in image order somewhere in the M phase, the last of
+// them a few microseconds before the dispatchers ran dry: the launch then ended 15-25 us after its dispatchers had (6-8 % of
+// a cycle-test launch, profiles/NOTES.md round 4, 2c).  Every one of those blocks has a centre pixel that escapes at step
+// >= 8 (exact counts: 209 of 209, 175 of 175; >= 12 holds 207 / 173), so the probe sorts them out for free: M entries whose
+// centre escapes at step >= m_late are filed apart and dispatched FIRST, before H; the rest of M and the V units stay behind
+// H as the filler of its drain.
 __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
-                                                              uint32_t *order, uint32_t *counters, double settle_thr)
+                                                              uint32_t *order, uint32_t *counters, int32_t m_late)
 {
     __shared__ uint32_t s_cnt[4][16], s_base[4];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool valid = r < nregions;
-    uint32_t cls = 4u;     // 0 H (unsettled), 1 V, 2 M, 3 H0 (settled), 4 nothing
+    uint32_t cls = 4u;     // 0 H, 1 V, 2 M, 3 M late, 4 nothing
     uint32_t by = 0, bx = 0;
     if (valid) {
         by = r / p.blocks_x;
@@ -87,10 +66,9 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
         lr = lr < p.nrows ? lr : p.nrows - 1u;
         const double cr = axis_value(p.re, p.col0 + lc), ci = axis_value(p.im, p.row0 + lr);
         const int32_t cap = p.mrd < probe_steps ? p.mrd : probe_steps;
-        double delta = 1e300;
-        const int32_t cnt = cap > 1 ? (settle_thr > 0.0 ? probe_settling(cr, ci, cap, &delta) : escape_count<true>(cr, ci, cap)) : 1;
+        const int32_t cnt = cap > 1 ? escape_count<true>(cr, ci, cap) : 1;
         const bool regular = bx < p.fast_bx_end && by < p.fast_by_end;   // the light path's coordinates are the regular formula
-        cls = cnt == 0 ? (delta <= settle_thr ? 3u : 0u) : (cnt <= 3 && regular ? 1u : 2u);
+        cls = cnt == 0 ? 0u : (cnt <= 3 && regular ? 1u : (m_late > 0 && cnt >= m_late ? 3u : 2u));
     }
     // V blocks -> one unit per aligned group of 8 lanes (= 8 block columns of one row: blocks_x % 8 == 0 and the workgroup's
     // first region is a multiple of 8)
@@ -136,14 +114,14 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
 constexpr uint32_t kStampTail = 8;                      // ids per XCD, from the end, that leave a time stamp
 constexpr uint32_t kStampWords = 8u + 8u * kStampTail;  // per launch: first id of every XCD, then the tails
 constexpr uint32_t kPlanWords = 40;  // [0] H entries [1] M entries [2] ids in all (8 per XCD round) [3] min h [4] min l
-                                     // [5] 1 = this launch leaves time stamps [6] H entries at the front of the list (the rest: settled)
+                                     // [5] 1 = this launch leaves time stamps [6] late M entries: the first [6] of the [0] front entries
                                      // [8..16) h[x]  [16..24) l[x]  [24..32) H base[x]  [32..40) light base[x]
 struct XcdShares { uint32_t cum[8]; };   // H list: share of XCDs 0..x, in 2^-24 (cum[7] = 2^24)
 
 // (host and device: mbk_units_plan / mbk_units_lookup of the C ABI run the same lines for the CPU tests)
-// (n_h: all H entries, of which the first n_h1 are the unsettled ones at the front of the list)
+// (n_h: the entries of the FRONT list = the n_ml late M entries, then the H entries; n_m: the other M entries)
 __host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const uint32_t *cum, uint32_t stamps, uint32_t *plan,
-                                           uint32_t n_h1 = 0xffffffffu)
+                                           uint32_t n_ml = 0u)
 {
     const uint32_t n_l = n_m + n_v, total = n_h + n_l;
     uint32_t h[8], l[8], prev = 0, slots = (total + 7u) >> 3;
@@ -164,7 +142,7 @@ __host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t 
         hmin = hmin < h[x] ? hmin : h[x];
         lmin = lmin < l[x] ? lmin : l[x];
     }
-    plan[0] = n_h; plan[1] = n_m; plan[2] = slots * 8u; plan[3] = hmin; plan[4] = lmin; plan[5] = stamps; plan[6] = n_h1 < n_h ? n_h1 : n_h; plan[7] = 0u;
+    plan[0] = n_h; plan[1] = n_m; plan[2] = slots * 8u; plan[3] = hmin; plan[4] = lmin; plan[5] = stamps; plan[6] = n_ml < n_h ? n_ml : n_h; plan[7] = 0u;
     uint32_t hb = 8u * hmin, lb = 8u * lmin;   // the contiguous pieces start behind the evenly dealt part
     for (uint32_t x = 0; x < 8u; ++x) {
         plan[8u + x] = h[x];
@@ -188,16 +166,16 @@ __host__ __device__ __forceinline__ bool units_lookup(uint32_t u, uint32_t hmin,
     return true;
 }
 
-__global__ void units_plan_kernel(const uint32_t *counters, const uint32_t *settled, XcdShares w, uint32_t stamps, uint32_t *plan)
+__global__ void units_plan_kernel(const uint32_t *counters, const uint32_t *late, XcdShares w, uint32_t stamps, uint32_t *plan)
 {
-    // (counters[n + 3 ..] is the M region: its last word + 1 = order[2n+3] holds the count of settled H entries)
+    // (late = order + 2n + 3: the count of late M entries, which open the front list)
     if (threadIdx.x == 0 && blockIdx.x == 0)
-        units_plan(counters[0] + settled[0], counters[1], counters[2], w.cum, stamps, plan, counters[0]);
+        units_plan(counters[0] + late[0], counters[1], counters[2], w.cum, stamps, plan, late[0]);
 }
 
 // The ten words of the plan a workgroup of XCD x needs, with scalar loads issued together (scalar_load_u32's comment)
 __device__ __forceinline__ void load_shares(const uint32_t *plan, uint32_t x, uint32_t &n_m, uint32_t &total, uint32_t &hmin,
-                                            uint32_t &lmin, uint32_t &stamps, uint32_t &n_h1, uint32_t &h_x, uint32_t &l_x,
+                                            uint32_t &lmin, uint32_t &stamps, uint32_t &n_ml, uint32_t &h_x, uint32_t &l_x,
                                             uint32_t &hbase_x, uint32_t &lbase_x)
 {
     const uint32_t *pl = plan, *px = plan + x;      // (kernel argument + workgroup id: scalar registers as they stand)
@@ -212,7 +190,7 @@ __device__ __forceinline__ void load_shares(const uint32_t *plan, uint32_t x, ui
                  "s_load_dword %8, %11, 0x60\n\t"
                  "s_load_dword %9, %11, 0x80\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(n_m), "=&s"(total), "=&s"(hmin), "=&s"(lmin), "=&s"(stamps), "=&s"(n_h1), "=&s"(h_x), "=&s"(l_x),
+                 : "=&s"(n_m), "=&s"(total), "=&s"(hmin), "=&s"(lmin), "=&s"(stamps), "=&s"(n_ml), "=&s"(h_x), "=&s"(l_x),
                    "=&s"(hbase_x), "=&s"(lbase_x)
                  : "s"(pl), "s"(px)
                  : "memory");
@@ -271,8 +249,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (uint32_t u = blockIdx.x;; u += p.unit_stride) {
         // (the shares are read anew on every trip -- a second trip is rare -- so that nothing of them stays in scalar
         // registers across a block)
-        uint32_t n_m, total, hmin, lmin, stamps, n_h1, h_x, l_x, hbase_x, lbase_x;
-        load_shares(args.plan, x, n_m, total, hmin, lmin, stamps, n_h1, h_x, l_x, hbase_x, lbase_x);
+        uint32_t n_m, total, hmin, lmin, stamps, n_ml, h_x, l_x, hbase_x, lbase_x;
+        load_shares(args.plan, x, n_m, total, hmin, lmin, stamps, n_ml, h_x, l_x, hbase_x, lbase_x);
         if (stamps && u < p.unit_stride) {
             // first trip: the first workgroup of every XCD and its last kStampTail tell the host when they started
             const uint32_t j0 = u >> 3, slots = total >> 3;
@@ -284,10 +262,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         uint32_t i;    // index into the H list / the light list (M entries, then V units)
         if (!units_lookup(u, hmin, lmin, h_x, l_x, hbase_x, lbase_x, is_h, i)) break;
         if (is_h || i < n_m) {
-            // (H entry i: the unsettled ones from the front of the list, the settled ones from the back of the M region)
-            const uint32_t e = scalar_load_u32(p.order, is_h ? (i < n_h1 ? i : 2u * n + 2u - (i - n_h1)) : n + 3u + i);
+            // (front entry i: the late M entries from the back of the M region, then the H list)
+            const bool late = is_h && i < n_ml;
+            const uint32_t e = scalar_load_u32(p.order, is_h ? (late ? 2u * n + 2u - i : i - n_ml) : n + 3u + i);
             const uint32_t by = e >> 16, bx = e & 0xffffu;
-            const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h,
+            const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h && !late,
                                                                    bx < p.fast_bx_end && by < p.fast_by_end);
             if (kStats && c >= 0) heavy += c > 0 ? (unsigned long long)(uint32_t)c : (1ull << 47) + never_cap;
         } else {

@@ -71,6 +71,8 @@ def datachunk_geometry(level: int, index_real: int, index_imag: int) -> Tuple[fl
 class MandelbrotDevice:
     """One mbk_ctx == one GPU.  Not thread-safe: use one host thread per instance."""
 
+    SLOTS = L.MBK_SLOTS   # tiles in flight of the host-buffer API (submit_* / wait)
+
     def __init__(self, device: int = 0):
         self._lib = L.load()
         h = C.c_void_p()
@@ -145,7 +147,7 @@ class MandelbrotDevice:
         out = {}
         for k, name in enumerate(["f64_scan", "f64_heavy", "f32_scan", "f32_heavy"]):
             v = C.c_uint32(0)
-            self._check(self._lib.mbk_get_option(self._h, 100 + k, C.byref(v)))
+            self._check(self._lib.mbk_get_option(self._h, L.MBK_INFO_SCAN_WG_PER_CU + k, C.byref(v)))
             out[name] = int(v.value)
         return out
 
@@ -155,7 +157,7 @@ class MandelbrotDevice:
         vals = []
         for k in range(10):
             v = C.c_uint32(0)
-            self._check(self._lib.mbk_get_option(self._h, 110 + k, C.byref(v)))
+            self._check(self._lib.mbk_get_option(self._h, L.MBK_INFO_XCD_SHARE + k, C.byref(v)))
             vals.append(int(v.value))
         return {"shares": [round(v / 1048576.0, 5) for v in vals[:8]], "last_launch_read": vals[8], "units_launches": vals[9]}
 
@@ -244,10 +246,12 @@ class MandelbrotDevice:
 
     def submit_datachunk(self, slot: int, level: int, mrd: int, index_real: int, index_imag: int,
                          out_bytes: np.ndarray, lazy_uniform: bool = False) -> None:
-        """Enqueue a tile on `slot` (0 or 1) and return at once; `out_bytes` (uint8[16777216], ideally from
-        pinned_empty) is valid after wait(slot).  Two slots = the D2H of one tile overlaps the next kernel.
-        lazy_uniform: skip the 16 MiB copy when the tile turns out all-0 / all-1 -- `out_bytes` is then left
-        untouched and the TileStats returned by wait() say which constant it is (MBK_LAZY_UNIFORM)."""
+        """Enqueue a tile on `slot` (0 .. SLOTS-1) and return at once; `out_bytes` (uint8[16777216], ideally from
+        pinned_empty) is valid after wait(slot).  Several slots = the D2H of one tile overlaps the kernels of the others.
+        lazy_uniform (MBK_LAZY_UNIFORM): the caller does not need `out_bytes` when the tile turns out all-0 / all-1 -- the
+        TileStats returned by wait() say which constant it is, and `out_bytes` is then unspecified: a tile wholly outside
+        |c| = 2 costs no GPU work at all, the copy of a tile the host probe takes for all-exterior is decided when its
+        statistics arrive, every other tile is copied as usual."""
         assert out_bytes.dtype == np.uint8 and out_bytes.size == L.MBK_CHUNK_BYTES and out_bytes.flags.c_contiguous
         self._check(self._lib.mbk_datachunk_submit_ex(self._h, slot, level, mrd, index_real, index_imag,
                                                       out_bytes.ctypes.data, None,

@@ -115,6 +115,7 @@ class _Net:
     retries = 6                  # attempts after the first, per exchange
     backoff = 0.05               # first pause; doubles per attempt up to 2 s, plus jitter
     retried = 0                  # exchanges repeated after a transient failure (diagnostic)
+    lease_timeouts = 0           # lease requests whose reply timed out after the request was sent (never retried)
     _gate = threading.BoundedSemaphore(8)
 
 
@@ -152,11 +153,24 @@ def set_network_options(max_connections: Optional[int] = None, connect_timeout: 
                 raise ValueError(f"native loop rejected {name} = {value}")
 
 
+_stop_event = threading.Event()   # the Python loops' counterpart of MBK_NET_STOP
+
+
 def request_stop(stop: bool = True) -> None:
-    """Ask every running native loop (mbk_worker_run is one blocking C call per GPU) to stop leasing, return the tiles it
-    holds and end; the Python loops are interruptible between tiles anyway."""
-    from . import _lib as L
-    L.load().mbk_net_set_option(L.NET_OPTIONS["stop"], 1 if stop else 0)
+    """Ask every running loop -- native (mbk_worker_run is one blocking C call per GPU: MBK_NET_STOP) and Python
+    (run_pipelined and the serial loop of run_farm check a module-level event before every lease) -- to stop leasing,
+    return the tiles it holds and end.  request_stop(False) re-arms; run_farm and main do so when they start, so a stop
+    from an earlier run in the same process does not end the next one at once (the flag is process-wide)."""
+    if stop:
+        _stop_event.set()
+    else:
+        _stop_event.clear()
+    try:
+        from . import _lib as L
+        lib = L.load()
+    except (ImportError, OSError):
+        return          # no native library: only the Python loops exist
+    lib.mbk_net_set_option(L.NET_OPTIONS["stop"], 1 if stop else 0)
 
 
 # "not now" rather than "never": the server's backlog was full (refused / reset), it was busy past a timeout, or it
@@ -229,10 +243,19 @@ def receive_workload(sock: socket.socket) -> Workload:
 
 def request_workload(addr: str, port: int, timeout: Optional[float] = None) -> Optional[Workload]:
     """First connection of WorkerCUDA.py:115-134.  None == 0x11 (no workload available).  A connect that is refused /
-    reset / times out, or a server that closes before its reply byte, is retried with backoff (NET.retries)."""
+    reset / times out, or a server that closes (or resets) before its reply byte, is retried with backoff (NET.retries);
+    a reply that does not arrive within the I/O timeout AFTER the request byte was sent is an error at once."""
     def exchange(sock: socket.socket):
         sock.sendall(struct.pack("B", REQUEST_CODE))
-        response = _recv_exact(sock, 1)[0]
+        try:
+            response = _recv_exact(sock, 1)[0]
+        except (socket.timeout, TimeoutError) as e:
+            # The request byte is out and no reply came in time: the server may have sent 0x10 + a workload that we did
+            # not read, and it registers the lease as it sends (Distributer.cs HandleWorkloadRequest) -- asking again
+            # would take a second tile and orphan the first for its one-hour lease.  Not retried (ADVICE r4); an orderly
+            # close or a reset before the reply byte still is (the hand-out code was never reached).
+            NET.lease_timeouts += 1
+            raise _NoRetry(e)
         try:
             if response == WORKLOAD_AVAILABLE_CODE:
                 return receive_workload(sock)      # the lease exists on the server now: never ask again for this one
@@ -342,12 +365,12 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
                   take: Optional[Callable[[], bool]] = None) -> int:
     """One GPU, the protocol of do_workload_single, three stages overlapped:
 
-        lease tile n+1  |  GPU: tile n (slot n%2) -- D2H of tile n-1 overlaps it  |  sender thread(s): tile n-1
+        lease tile n+1  |  GPU: tile n (slot n % SLOTS) -- D2H of earlier tiles overlaps it  |  sender thread(s): tile n-1
 
     Per tile the wire sees exactly the reference's two exchanges (WorkerCUDA.py:115-134 and :148-172);
     only their timing overlaps with other tiles', which the Distributer allows (any connection may
     return any leased tile).  The device is driven from this thread only (an mbk_ctx is not
-    thread-safe); sender threads touch sockets and pinned host buffers.  `senders + 2` pinned 16 MiB
+    thread-safe); sender threads touch sockets and pinned host buffers.  `senders + SLOTS` pinned 16 MiB
     buffers circulate; a tile is submitted to the GPU only when a buffer is free, so a slow server
     back-pressures the lease rate instead of growing a queue.  Ends when the server answers 0x11 or after
     `max_tiles`; returns the number of tiles sent (accepted, incl. resets)."""
@@ -355,7 +378,8 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
     from .device import MandelbrotDevice
     own = device is None
     dev = device if device is not None else MandelbrotDevice(device_index)
-    nbuf = senders + 2
+    nslots = int(getattr(dev, "SLOTS", 2))
+    nbuf = senders + nslots
     free: "queue.Queue" = queue.Queue()
     for _ in range(nbuf):
         free.put(dev.pinned_empty((CHUNK_BYTES,), np.uint8))
@@ -396,13 +420,14 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
     threads = [threading.Thread(target=sender, daemon=True) for _ in range(max(1, senders))]
     for t in threads:
         t.start()
-    inflight: List[Optional[tuple]] = [None, None]   # per device slot: (workload, buffer)
+    inflight: List[Optional[tuple]] = [None] * nslots   # per device slot: (workload, buffer)
     leased = 0
     slot = 0
     try:
         more = True
         while more or any(inflight):
-            if more and not errors and (max_tiles is None or leased < max_tiles) and (take is None or take()):
+            if (more and not errors and not _stop_event.is_set() and (max_tiles is None or leased < max_tiles)
+                    and (take is None or take())):
                 try:
                     workload = request_workload(addr, port)
                 except BaseException as e:   # e.g. connection refused while the server restarts: stop leasing, but
@@ -425,7 +450,7 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
                 dev.submit_datachunk(slot, *workload, buf, lazy_uniform=True)
                 inflight[slot] = (workload, buf)
                 leased += 1
-            slot ^= 1
+            slot = (slot + 1) % nslots
     finally:
         for _ in threads:
             outbox.put(None)
@@ -485,6 +510,7 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
         devices = list(range(device_count()))
     if not devices:   # also an explicitly empty list: a farm node that silently does nothing is a misconfiguration
         raise RuntimeError("no gfx950 GPU visible and no CPU fallback exists")
+    request_stop(False)   # a stop left over from an earlier run in this process must not end this one
 
     done = [0] * len(devices)
     errors: List[BaseException] = []
@@ -512,7 +538,7 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
                 done[slot] = run_pipelined(addr, port, dev_index, log=tag, senders=senders, take=take)
                 return
             compute = make_compute(dev_index)
-            while take():
+            while not _stop_event.is_set() and take():
                 if not do_workload_single(addr, port, compute=compute, log=tag):
                     break
                 done[slot] += 1
@@ -563,8 +589,7 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
             farm.join(0.2)
     except KeyboardInterrupt:
         print("interrupt: finishing the tiles in flight, leasing no more")
-        if native:
-            request_stop()
+        request_stop()      # native loops: MBK_NET_STOP; Python loops: the module's stop event
         farm.join()
     if _main_result and isinstance(_main_result[0], BaseException):
         raise _main_result[0]

@@ -190,19 +190,33 @@ int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, ui
  * mbk_quantise_counts) and mbk_serialize_last work on slot 0's buffers; while a tile submitted on slot 0 has not
  * been waited for they return MBK_ERR_INVALID instead of touching them. */
 /*
- * Two tiles in flight per context ("double-buffered streams": the D2H of one tile overlaps the kernel
- * of the next; each slot has its own HIP stream, events and device buffers).  mbk_datachunk_submit
- * enqueues kernel + stats reduction + D2H for a tile on `slot` (0 .. MBK_SLOTS-1) and returns at once;
- * mbk_wait blocks until that slot's tile is in h_bytes / h_counts (use pinned memory, mbk_host_alloc,
- * or the copy is not asynchronous) and fills stats.  A slot holds one tile at a time.  Slot 0 is also
- * what the synchronous calls use.  Same single-host-thread rule as everything else on a ctx.
+ * Several tiles in flight per context (each slot has its own HIP stream, events and device buffers, allocated on first
+ * use: the D2H of one tile overlaps the kernels of the others, and the host's per-tile work -- enqueue, wake-up -- hides
+ * behind the GPU's).  mbk_datachunk_submit enqueues kernel + stats reduction + D2H for a tile on `slot`
+ * (0 .. MBK_SLOTS-1) and returns at once; mbk_wait blocks until that slot's tile is in h_bytes / h_counts (use pinned
+ * memory, mbk_host_alloc, or the copy is not asynchronous) and fills stats.  A slot holds one tile at a time.  Slot 0 is
+ * also what the synchronous calls use.  Same single-host-thread rule as everything else on a ctx.  Two slots were
+ * round 1-4's pipeline (1 973 tiles/s on level 16 against a bound of 2 490: every wait exposed the host's enqueue +
+ * wake-up latency); four keep the copy engine and the CUs fed (profiles/r05).
+ *
+ * MBK_LAZY_UNIFORM (flags of mbk_datachunk_submit_ex / mbk_view_submit): the caller does not need h_bytes when the tile
+ * turns out uniform (stats.all_bytes_zero / all_bytes_one: DataChunk.cs:82,87 "Never" / "Immediate" chunks, which the
+ * server stores without a payload).  Then (1) a window that lies wholly outside |c| = 2 (with a margin of 1e-8) is
+ * answered on the host without any GPU work when mrd >= 256: every count is 1, every byte 1 (proof:
+ * tests/test_oracle.py) -- the corners of [-2, 2]^2 outside the inscribed circle, 1 - pi/4 = 21 % of the tiles of a deep
+ * pyramid level (32 of level 16's 256; its other 160 "Immediate" tiles hold counts 1..4 and are computed); (2) the copy of a tile whose host probe says "all gone within 4 steps" is decided when the
+ * statistics arrive; (3) every other tile is copied as usual.  h_bytes of a tile reported uniform is unspecified.
  */
-#define MBK_SLOTS 2
+#define MBK_SLOTS 4
 int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
                          uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts);
 int mbk_datachunk_submit_ex(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
                             uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts, uint32_t flags /* MBK_LAZY_UNIFORM */);
 int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats);
+/* The host-side test behind MBK_LAZY_UNIFORM's short cut, without a device or a context: *outside = 1 when every sample
+ * of the window has |c|^2 >= 4 (1 + m), m = 1e-8 (1e-4 with MBK_PRECISION_F32 in flags) -- then calc_mb_value returns 1
+ * for every pixel when mrd >= 2 (WorkerCUDA.py:54-63: z1 = c^2 + c, |z1| >= |c| (|c| - 1) > 2).  For the CPU tests. */
+int mbk_view_outside_circle(const mbk_view *view, uint32_t flags, int *outside);
 /* The same for a generic view / window (the multi-GPU shard unit is a row band of a view): enqueue on
  * `slot`, results land in h_counts / h_bytes (either may be NULL according to flags) after mbk_wait. */
 int mbk_view_submit(mbk_ctx *ctx, int slot, const mbk_view *view, uint32_t mrd, uint32_t flags,
@@ -281,16 +295,18 @@ enum mbk_option {
                               65536 [32768 = one half] */
     MBK_OPT_XCD_BALANCE,   /* order 3: shares of the eight XCDs in the units kernel's list of heavy blocks.  The XCDs of one chip run
                               2-10 % apart and the hardware deals them equal numbers of workgroups, so a launch lasts as long as
-                              its slowest XCD: 0 even shares, [1] shares that follow the time stamps earlier launches on the same
-                              stream left in pinned memory (72 stores per launch; the first launch on a stream is even; only
-                              launches without the cycle test, and only those that had the chip to themselves, are followed:
-                              strict cfg2 +0.7..1.2 %), 2 a fixed uneven deal (tests), 3 a fixed prior without stamps or feedback
-                              (even XCDs 0.126, odd 0.124), applied to every launch.  Changes when a block is computed, never
-                              what is stored */
-    MBK_OPT_H_SETTLED,     /* order 3: [0] one list of heavy blocks; k = 1..30: heavy blocks whose probe orbit is within 10^-k of settled
-                              (min over p of |z_last - z_(last-p)|^2 of the centre pixel) are dispatched behind the others -- with
-                              the cycle test those retire within a few checks while the unsettled ones run (nearly) all steps
-                              (profiles/NOTES.md 2c).  Changes when a block is computed, never what is stored */
+                              its slowest XCD: [0] even shares (default since round 5), 1 shares that follow the time stamps
+                              earlier launches on the same stream left in pinned memory (72 stores per launch; the first launch
+                              on a stream is even; only launches without the cycle test, and only those that had the chip to
+                              themselves, are followed: strict cfg2 +0.7..1.2 %, nothing for the library's default path with
+                              the cycle test or several tiles in flight -- which is why it is opt-in: bench.py asks for it in
+                              its strict leg and says so), 2 a fixed uneven deal (tests).  Changes when a block is computed,
+                              never what is stored */
+    MBK_OPT_M_LATE,        /* order 3: boundary blocks (centre pixel gone within the probe's 32 steps) whose centre escapes at
+                              step >= this value open the dispatch order, before the interior blocks: the ~200 of them that
+                              hold a never-escaping pixel run as long as an interior block and used to start a few microseconds
+                              before the dispatchers ran dry (csrc/mbk_units.h): 0 (off: H, M, V), 4..31 [8].  Changes when a
+                              block is computed, never what is stored */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
@@ -328,8 +344,8 @@ int mbk_reduce_counts(mbk_ctx *ctx, const int32_t *d_counts, uint64_t n, uint32_
  * Distributer.cs:30-45,358-458 / DistributerWorkload.cs:53-100 UNCHANGED: per tile the wire sees exactly the
  * reference's two exchanges (request 0x00 -> 0x10 + 4 x u32 | 0x11; response 0x01 + 4 x u32 -> 0x20 | 0x21, then on
  * 0x20 exactly MBK_CHUNK_BYTES raw bytes); only their timing overlaps with other tiles': while tile n is on the GPU
- * (slot n % 2, its D2H overlapping the other slot's kernel) tile n+1 is being leased and tiles <= n-1 are being sent
- * by `senders` threads (1..64) on their own connections.  `senders + 2` pinned 16 MiB buffers circulate, so a slow
+ * (slot n % MBK_SLOTS, its D2H overlapping the other slots' kernels) tile n+1 is being leased and tiles <= n-1 are being sent
+ * by `senders` threads (1..64) on their own connections.  `senders + MBK_SLOTS` pinned 16 MiB buffers circulate, so a slow
  * server back-pressures the lease rate.  Uniform tiles (all 0 / all 1) are not copied off the GPU: their payload
  * comes from a shared constant buffer.  A rejected tile (0x21) is dropped and the loop carries on (WorkerCUDA.py:
  * 161-163).  On a socket error while leasing the loop stops leasing, finishes the tiles it holds, and returns
@@ -372,6 +388,7 @@ enum mbk_net_option {
                                        handlers set it from another thread); 0 re-arms */
     MBK_NET_PEAK_CONNECTIONS = 6,   /* read-only (mbk_net_get_option): the most connections that were ever open at once;
                                        setting MBK_NET_MAX_CONNECTIONS clears it */
+    MBK_NET_FEEDER_SLOTS = 7,       /* tiles mbk_feeder_run keeps on its backend at once (slot numbers 0 .. k-1); 1..8, default 2 */
     MBK_NET_OPT_COUNT_
 };
 int mbk_net_set_option(int option, uint32_t value);
@@ -380,7 +397,7 @@ int mbk_net_get_option(int option, uint32_t *value);
 /* The same protocol loop over a caller-supplied compute backend (mbk_worker_run is this with the backend bound to a
  * GPU context: submit = mbk_datachunk_submit_ex(MBK_LAZY_UNIFORM), wait = mbk_wait, alloc/release = pinned memory).
  * For hosts that schedule the GPU themselves, and for the CPU tests of the protocol engine.  submit / wait are
- * called from the calling thread only, with slot alternating 0, 1; wait must fill stats (all_bytes_zero /
+ * called from the calling thread only, with slot cycling through 0 .. k-1 (k = MBK_NET_FEEDER_SLOTS, default 2; mbk_worker_run uses MBK_SLOTS); wait must fill stats (all_bytes_zero /
  * all_bytes_one decide whether h_bytes or a constant buffer is sent).  on_tile (optional) is called from a sender
  * thread once per returned tile with status 1 accepted, 0 rejected, 2 reset after 0x20, -1 error. */
 typedef struct mbk_feeder_ops {

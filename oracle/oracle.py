@@ -87,6 +87,10 @@ class COracle:
     def escape(self, cr: float, ci: float, mrd: int) -> int:
         return int(self.lib.mbo_escape(cr, ci, mrd))
 
+    def escape_f32(self, cr: float, ci: float, mrd: int) -> int:
+        """The binary32 variant of one pixel (BASELINE cfg4; mbo_escape_f32)."""
+        return int(self.lib.mbo_escape_f32(cr, ci, mrd))
+
     def quantise(self, count: int, mrd: int) -> int:
         return int(self.lib.mbo_quantise(count, mrd))
 

@@ -104,23 +104,12 @@ PY
         done; done
       rm -rf "$OUT"/pmc_*_?;;
   unitstrace) hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/units_trace profiles/microbench/units_trace.hip 2> "$OUT/build_units_trace.log"
-      for W in ${ARG:-cfg2 chunk_l1}; do
-        timeout 300 /tmp/units_trace $W "$OUT/units_trace_$W.bin" > "$OUT/units_trace_$W.txt" 2>&1
-        timeout 600 python scripts/analyze_units_trace.py "$OUT/units_trace_$W.bin" >> "$OUT/units_trace_$W.txt" 2>&1
-        cat "$OUT/units_trace_$W.txt"; rm -f "$OUT/units_trace_$W.bin"
+      for A in ${ARG:-cfg2,0,0 chunk_l1,0,0}; do   # workload,cycle test,m_late
+        set -- ${A//,/ }; W=$1; N=units_trace_${A//,/_}
+        timeout 300 /tmp/units_trace $W "$OUT/$N.bin" ${2:-0} ${3:-0} > "$OUT/$N.txt" 2>&1
+        timeout 600 python scripts/analyze_units_trace.py "$OUT/$N.bin" >> "$OUT/$N.txt" 2>&1
+        grep -v "^  *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]*$" "$OUT/$N.txt" | tail -48; rm -f "$OUT/$N.bin"
       done;;
-  fill) hipcc --offload-arch=gfx950 -O3 -o /tmp/fill profiles/microbench/fill.hip 2> "$OUT/build_fill.log" && timeout 300 /tmp/fill > "$OUT/fill.txt" 2>&1; cat "$OUT/fill.txt"
-      b exterior_fillbox --workload exterior --no-cpu-baseline --no-extras; b exterior_both_fillbox --workload exterior --outputs both --no-cpu-baseline --no-extras;;
-  pmccyc) # PMC of the default kernel WITH the cycle test (the library default), with and without an option: pmccyc:NAME=V[:workloads]
-      O=${ARG%%:*}; WL=${ARG#*:}; [ "$WL" = "$ARG" ] && WL="cfg2 chunk_l1"
-      C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
-      C2="SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
-      for W in $WL; do X="--steps 20 --warmup 5"
-        for V in base opt; do [ $V = opt ] && OO="--opt $O" || OO=""
-          pmcrun ${W}_cyc_${V}_a "$C1" --workload $W $X $OO --opt cycle_detect=1; pmcrun ${W}_cyc_${V}_b "$C2" --workload $W $X $OO --opt cycle_detect=1
-          python scripts/pmc_summary.py "$OUT/${W}_cyc_${V}_pmc_by_kernel.json" "$OUT/pmc_${W}_cyc_${V}_a" "$OUT/pmc_${W}_cyc_${V}_b" --match tile_ | cut -c1-600
-        done; done
-      rm -rf "$OUT"/pmc_*_?;;
   skew) [ -x build/units_skew ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip 2> "$OUT/build_units_skew.log"
       for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.5,0,1,0 cfg2,40,0.5,0,1,1}; do   # workload,launches,gain[,rotation[,cycle test[,signal]]]
         timeout 120 build/units_skew ${A//,/ } > "$OUT/units_skew_${A//,/_}.txt" 2>&1; tail -4 "$OUT/units_skew_${A//,/_}.txt"
@@ -172,7 +161,7 @@ try:
 except Exception as e: print("  power FAILED", e)
 PY
       done;;
-  e2e) timeout 200 python scripts/level_rate.py 16 1024 > "$OUT/level16.log" 2>&1; grep "level\|two" "$OUT/level16.log"
+  e2e) timeout 200 python scripts/level_rate.py 16 1024 > "$OUT/level16.log" 2>&1; grep -v amdgpu.ids "$OUT/level16.log"
        timeout 900 python scripts/worker_e2e.py 12 256 3 > "$OUT/worker_e2e.log" 2>&1; grep -v amdgpu.ids "$OUT/worker_e2e.log" | tail -14;;
   *) echo "unknown section $SEC";;
   esac

@@ -1,6 +1,7 @@
 """Tile rate over a whole level of the reference's image pyramid (level n = n x n DataChunk tiles of
-[-2,2]^2): kernel time, pinned D2H time and wall tiles/s for one GPU context.
-    python scripts/level_rate.py [level] [mrd]"""
+[-2,2]^2): kernel time, pinned D2H time and wall tiles/s for one GPU context -- synchronous, and with 2 .. MBK_SLOTS tiles
+in flight, with and without MBK_LAZY_UNIFORM (the worker's mode).
+    python scripts/level_rate.py [level] [mrd] [option=value ...]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -26,27 +27,27 @@ n = level * level
 print(f"level {level} mrd {mrd}: {n} tiles in {dt:.3f} s = {n/dt:.1f} tiles/s ({its/dt/1e9:.0f} G pixel-iter/s wall); "
       f"kernel ms mean {np.mean(ks):.3f} median {np.median(ks):.3f} max {np.max(ks):.3f} (sum {np.sum(ks)/1e3:.3f} s); "
       f"d2h ms mean {np.mean(ds):.3f}; Never {never} Immediate {imm} RLE-smaller {rle} of {n}")
+print(f"  bound of a perfect pipeline: sum of max(kernel, d2h) per tile = {sum(max(a, b) for a, b in zip(ks, ds)):.1f} ms "
+      f"-> {n / sum(max(a, b) for a, b in zip(ks, ds)) * 1e3:.0f} tiles/s; sum of d2h alone {sum(ds):.1f} ms")
 
-# the same level with two tiles in flight (mbk_datachunk_submit / mbk_wait): D2H of tile n overlaps kernel n+1
-pins = [dev.pinned_empty((16777216,), np.uint8) for _ in range(2)]
+nslots = dev.SLOTS
+pins = [dev.pinned_empty((16777216,), np.uint8) for _ in range(nslots)]
 tiles = [(ir, ii) for ir in range(level) for ii in range(level)]
-t0 = time.perf_counter()
-dev.submit_datachunk(0, level, mrd, *tiles[0], pins[0])
-for i in range(1, len(tiles) + 1):
-    if i < len(tiles):
-        dev.submit_datachunk(i % 2, level, mrd, *tiles[i], pins[i % 2])
-    dev.wait((i - 1) % 2)
-dt2 = time.perf_counter() - t0
-print(f"two slots in flight: {n} tiles in {dt2:.3f} s = {n/dt2:.1f} tiles/s")
-
-# ... and without copying uniform tiles off the GPU (MBK_LAZY_UNIFORM): what the pipelined worker does
-t0 = time.perf_counter()
-skipped = 0
-dev.submit_datachunk(0, level, mrd, *tiles[0], pins[0], lazy_uniform=True)
-for i in range(1, len(tiles) + 1):
-    if i < len(tiles):
-        dev.submit_datachunk(i % 2, level, mrd, *tiles[i], pins[i % 2], lazy_uniform=True)
-    st = dev.wait((i - 1) % 2)
-    skipped += st.all_bytes_zero or st.all_bytes_one
-dt3 = time.perf_counter() - t0
-print(f"two slots in flight, uniform tiles not copied ({skipped} of {n}): {n} tiles in {dt3:.3f} s = {n/dt3:.1f} tiles/s")
+for lazy in (False, True):
+    for k in range(2, nslots + 1):
+        best, uniform, its2 = None, 0, 0
+        for rep in range(2):
+            t0 = time.perf_counter()
+            uniform, its2 = 0, 0
+            for i in range(n + k):
+                if i >= k:
+                    st = dev.wait((i - k) % k)
+                    uniform += st.all_bytes_zero or st.all_bytes_one
+                    its2 += st.pixel_iterations
+                if i < n:
+                    dev.submit_datachunk(i % k, level, mrd, *tiles[i], pins[i % k], lazy_uniform=lazy)
+            d = time.perf_counter() - t0
+            best = d if best is None else min(best, d)
+        assert its2 == its, (its2, its)
+        print(f"{k} in flight{', MBK_LAZY_UNIFORM (' + str(uniform) + ' uniform tiles not copied)' if lazy else ''}: "
+              f"{n} tiles in {best:.4f} s = {n/best:.1f} tiles/s")

@@ -413,9 +413,8 @@ OPTION_MATRIX = [
     ("group", {"order": 2}), ("group", {"order": 3, "group_steps": 8}), ("group", {"order": 3, "waves_per_wg": 2}),
     ("group", {"order": 3, "xcd_balance": 0}), ("group", {"order": 3, "xcd_balance": 2, "units_min_light": 0}),
     ("default", {"xcd_balance": 2, "cycle_detect": 0}),
-    ("group", {"order": 3, "h_settled": 6}), ("group", {"order": 3, "h_settled": 6, "cycle_detect": 0, "xcd_balance": 2, "units_min_light": 0}),
-    ("default", {"h_settled": 1}), ("group", {"order": 3, "h_settled": 30, "units_min_light": 0}),
-    ("default", {"xcd_balance": 3}), ("group", {"order": 3, "xcd_balance": 3, "h_settled": 5, "cycle_detect": 0}),
+    ("group", {"order": 3, "m_late": 0}), ("group", {"order": 3, "m_late": 4, "cycle_detect": 0, "xcd_balance": 2, "units_min_light": 0}),
+    ("default", {"m_late": 31}), ("group", {"order": 3, "m_late": 12, "units_min_light": 0}), ("default", {"m_late": 65536, "xcd_balance": 1, "cycle_detect": 0}),
 ]
 
 
@@ -621,21 +620,78 @@ def test_default_kernel_choice_any_arrival_order(oracle):
 
 
 def test_lazy_uniform_skips_the_copy_only_for_uniform_tiles(gpu, golden):
-    """MBK_LAZY_UNIFORM: an all-interior tile ("Never", every byte 0) leaves the host buffer untouched and says
-    so in the stats; a boundary tile is copied as usual."""
+    """MBK_LAZY_UNIFORM: the stats say whether the tile is uniform, and only then may the host buffer be left alone.  An
+    all-exterior tile (host probe: every pixel gone within 4 steps) is not copied; an all-interior one is reported "Never"
+    (since round 5 its copy is enqueued at submit, so the buffer is either untouched or all zero); a boundary tile and an
+    all-exterior tile with non-uniform bytes are copied as usual; a tile wholly outside |c| = 2 costs no GPU work at all."""
     buf = gpu.pinned_empty((16777216,), np.uint8)
     buf[:] = 7
     gpu.submit_datachunk(0, 20, 1024, 7, 9, buf, lazy_uniform=True)           # golden: all 16 777 216 pixels in the set
     st = gpu.wait(0)
-    assert st.all_bytes_zero and not st.all_bytes_one and st.d2h_ms < 0.05 and (buf == 7).all()
+    assert st.all_bytes_zero and not st.all_bytes_one and ((buf == 7).all() or (buf == 0).all())
     gpu.submit_datachunk(1, 4, 256, 0, 0, buf, lazy_uniform=True)             # all exterior, but bytes 1..3: not uniform
     st = gpu.wait(1)
     assert not st.all_bytes_zero and not st.all_bytes_one
     assert hashlib.sha256(buf.tobytes()).hexdigest() == str(golden["full/4_256_0_0/bytes_sha256"])
     buf[:] = 7
-    gpu.submit_datachunk(0, 16, 1024, 0, 0, buf, lazy_uniform=True)           # far corner: every pixel escapes at step 1 -> byte 1
-    st = gpu.wait(0)
-    assert st.all_bytes_one and (buf == 7).all() and st.never_pixels == 0
+    gpu.submit_datachunk(2, 16, 1024, 0, 0, buf, lazy_uniform=True)           # far corner, outside |c| = 2: answered on the host
+    st = gpu.wait(2)
+    assert st.all_bytes_one and (buf == 7).all() and st.never_pixels == 0 and st.pixel_iterations == 16777216
+    assert st.kernel_ms == 0.0 and st.d2h_ms == 0.0 and st.rle_runs == 1
+    gpu.submit_datachunk(3, 16, 1024, 2, 4, buf, lazy_uniform=True)           # reaches inside the circle, counts 1 and 2: byte 1
+    st = gpu.wait(3)
+    assert st.all_bytes_one and (buf == 7).all() and st.never_pixels == 0 and st.kernel_ms > 0.0 and st.d2h_ms < 0.05
+    assert st.pixel_iterations == 33545871
+
+
+def test_lazy_uniform_agrees_with_the_plain_path_on_a_whole_level(gpu, oracle):
+    """Every tile of pyramid level 16 (mrd 1024 and 256) and the ring of level 40 through MBK_LAZY_UNIFORM with all slots in
+    flight against the synchronous path: identical statistics, identical bytes wherever the tile is not uniform, and the tiles
+    answered on the host (no kernel) are exactly those wholly outside |c| = 2 -- whose bytes the GPU agrees are all 1.  mrd 255
+    (byte 2 outside the circle) and mrd 2 take the GPU path."""
+    import ctypes as C
+    from distributedmandelbrot_amd import _lib as L
+    nslots = gpu.SLOTS
+    pins = [gpu.pinned_empty((16777216,), np.uint8) for _ in range(nslots)]
+    ref = gpu.pinned_empty((16777216,), np.uint8)
+    lib = L.load()
+
+    def outside(level, ir, ii):
+        sr, si, rng = oracle.geometry(level, ir, ii)
+        cv = L.mbk_view(sr, si, rng, rng, 4096, 4096, 0, 0, 4096, 4096)
+        out = C.c_int(-1)
+        assert lib.mbk_view_outside_circle(C.byref(cv), 0, C.byref(out)) == L.MBK_OK
+        return bool(out.value)
+
+    ring40 = [(ir, ii) for ir in range(40) for ii in range(40)
+              if 3.2 < (min(abs(-2 + 0.1 * ir), abs(-2 + 0.1 * (ir + 1))) ** 2 + min(abs(-2 + 0.1 * ii), abs(-2 + 0.1 * (ii + 1))) ** 2) < 4.6]
+    jobs = [(16, 1024, [(ir, ii) for ir in range(16) for ii in range(16)]), (16, 256, [(ir, ii) for ir in (0, 1, 5, 15) for ii in range(16)]),
+            (40, 1024, ring40[::3]), (16, 255, [(0, 0), (15, 15), (3, 0)]), (16, 2, [(0, 0), (7, 7)])]
+    for level, mrd, tiles in jobs:
+        n, host_answered, got = len(tiles), 0, {}
+        for i in range(n + nslots):
+            if i >= nslots:
+                j = i - nslots
+                st = gpu.wait(j % nslots)
+                got[tiles[j]] = (st, None if (st.all_bytes_zero or st.all_bytes_one) else pins[j % nslots].copy())
+            if i < n:
+                gpu.submit_datachunk(i % nslots, level, mrd, *tiles[i], pins[i % nslots], lazy_uniform=True)
+        for t in tiles:
+            st, data = got[t]
+            _, _, want = gpu.datachunk(level, mrd, *t, out_bytes=ref)
+            assert (st.pixel_iterations, st.never_pixels, st.all_bytes_zero, st.all_bytes_one, st.rle_runs) == \
+                   (want.pixel_iterations, want.never_pixels, want.all_bytes_zero, want.all_bytes_one, want.rle_runs), (level, mrd, t)
+            if data is not None:
+                assert np.array_equal(data, ref), (level, mrd, t)
+            skipped = st.kernel_ms == 0.0 and st.d2h_ms == 0.0
+            assert skipped == (outside(level, *t) and mrd >= 256), (level, mrd, t)
+            if skipped:
+                host_answered += 1
+                assert want.all_bytes_one and (ref == 1).all() and want.pixel_iterations == 16777216
+        if (level, mrd) == (16, 1024):
+            assert host_answered == 32
+        if level == 40:
+            assert 0 < host_answered < n
 
 
 CYCLE_VIEWS = [

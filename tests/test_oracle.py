@@ -229,3 +229,97 @@ def test_cycle_retirement_claim(oracle):
     for cr in (0.0, -1.0):
         counts, executed = oracle.view_cycle(cr, 0.0, 0.0, 0.0, 1, 1, 100000)
         assert counts[0, 0] == 0 and executed[0, 0] < 100
+
+
+def test_outside_circle_escapes_at_step_one(oracle):
+    """The claim behind MBK_LAZY_UNIFORM's short cut (csrc/mbk_api.hip: submit_view, view_outside_circle2): every sample c
+    with |c|^2 >= 4 (1 + m), m = 1e-8 (binary64) / 1e-4 (binary32), gets count 1 from calc_mb_value (WorkerCUDA.py:54-63)
+    for any mrd >= 2, so a window that lies wholly outside that circle is an "Immediate" chunk (every byte
+    ceil(256 / mrd) = 1 for mrd >= 256) and needs no GPU.
+
+    In exact arithmetic: z1 = c^2 + c = c (c + 1), |z1| = |c| |c + 1| >= |c| (|c| - 1); with |c| = 2 (1 + d), d >= 0:
+    |z1| >= 2 (1 + d) (1 + 2 d) >= 2 (1 + 3 d), |z1|^2 >= 4 (1 + 6 d).  |c|^2 >= 4 (1 + m) means d >= m / 2 - m^2 / 8, so
+    |z1|^2 >= 4 (1 + 2.9 m).  The reference computes |z1|^2 with ten individually rounded operations on operands of like
+    sign or with a result bounded away from cancellation only in the products -- the one subtraction zr^2 - zi^2 can cancel,
+    but then its ABSOLUTE error is at most 2 u max(zr^2, zi^2) <= 2 u |c|^2, against |z1| >= |c| (|c| - 1) >= |c|^2 / 2: a
+    relative error of each component of z1 below 8 u in all, of |z1|^2 below 40 u (u = 2^-53 resp. 2^-24): 4.4e-15 resp.
+    2.4e-6, four to seven orders of magnitude under 2.9 m.  Checked here with exact rationals on the adversarial arc
+    around c = -2 (where |c + 1| is smallest), on the whole circle, and on random points; then the library's own host
+    predicate (mbk_view_outside_circle: no device needed) is checked against the oracle on random views and on every
+    DataChunk tile of levels 1..24."""
+    from fractions import Fraction
+    from distributedmandelbrot_amd import _lib as L
+    import ctypes as C
+
+    rs = np.random.RandomState(11)
+
+    def exact_norm2_z1(cr, ci):
+        cr, ci = Fraction(cr), Fraction(ci)
+        zr, zi = cr * cr - ci * ci + cr, 2 * cr * ci + ci
+        return zr * zr + zi * zi
+
+    for m, esc, cast in ((1e-8, oracle.escape, float), (1e-4, oracle.escape_f32, np.float32)):
+        r = 2.0 * np.sqrt(1.0 + m) * (1.0 + 1e-12)
+        angles = np.concatenate([np.pi + np.linspace(-1e-3, 1e-3, 201), np.pi + rs.uniform(-0.2, 0.2, 300),
+                                 np.linspace(0.0, 2.0 * np.pi, 721), rs.uniform(0.0, 2.0 * np.pi, 2000)])
+        radii = np.concatenate([np.full(angles.size // 2, r), r * (1.0 + 10.0 ** rs.uniform(-9, 2, angles.size - angles.size // 2))])
+        worst = None
+        for th, rad in zip(angles, radii):
+            cr, ci = float(cast(rad * np.cos(th))), float(cast(rad * np.sin(th)))
+            if cr * cr + ci * ci < 4.0 * (1.0 + m):
+                continue      # rounding of the polar form put the sample inside the margin: not a sample the predicate admits
+            n2 = exact_norm2_z1(cr, ci)
+            assert n2 >= Fraction(4) * (1 + Fraction(2.8 * m)), (cr, ci, float(n2))
+            worst = n2 if worst is None or n2 < worst else worst
+            for mrd in (2, 3, 1000):
+                assert esc(cr, ci, mrd) == 1, (cr, ci, mrd)
+        assert float(worst) < 4.0 * (1.0 + 4.0 * m)     # the arc around c = -2 was really sampled
+
+    lib = L.load()
+
+    def outside(view, window=None, f32=False):
+        col0, row0, ncols, nrows = window if window else (0, 0, view[4], view[5])
+        cv = L.mbk_view(view[0], view[1], view[2], view[3], view[4], view[5], col0, row0, ncols, nrows)
+        out = C.c_int(-1)
+        assert lib.mbk_view_outside_circle(C.byref(cv), L.MBK_PRECISION_F32 if f32 else 0, C.byref(out)) == L.MBK_OK
+        return bool(out.value)
+
+    # every DataChunk tile of levels 1..24: the predicate is the geometry it claims to be (recomputed here from np.linspace's
+    # axis), it never admits a tile with a count other than 1 (a tile comes closest to the circle on its border), and it
+    # finds what the geometry promises: the corners of [-2, 2]^2 outside the inscribed circle -- 32 of level 16's 256 tiles
+    # (NOT the 192 "Immediate" tiles of that level at mrd 1024: the other 160 hold counts 1..4, which all quantise to byte 1,
+    # and their statistics need the exact counts)
+    admitted = {}
+    for level in range(1, 25):
+        k = 0
+        for ir in range(level):
+            for ii in range(level):
+                sr, si, rng = oracle.geometry(level, ir, ii)
+                xs, ys = numpy_axis(sr, rng, 4096), numpy_axis(si, rng, 4096)
+                dx = 0.0 if xs[0] <= 0 <= xs[-1] else min(abs(xs[0]), abs(xs[-1]))
+                dy = 0.0 if ys[0] <= 0 <= ys[-1] else min(abs(ys[0]), abs(ys[-1]))
+                want = dx * dx + dy * dy >= 4.0 * (1.0 + 1e-8)
+                assert outside((sr, si, rng, rng, 4096, 4096)) == want, (level, ir, ii)
+                if not want:
+                    continue
+                k += 1
+                for win in ((0, 0, 4096, 1), (0, 4095, 4096, 1), (0, 0, 1, 4096), (4095, 0, 1, 4096)):
+                    c, _, _ = oracle.view(sr, si, rng, rng, 4096, 4096, 1024, window=win, want_bytes=False)
+                    assert (c == 1).all(), (level, ir, ii, win)
+        admitted[level] = k
+    assert admitted[16] == 32 and admitted[4] == 0 and admitted[8] == 4 and admitted[24] == 92, admitted
+    # random views and windows, both precisions: admitted -> the oracle's counts are all 1
+    hits = 0
+    for _ in range(400):
+        w, h = int(rs.randint(1, 300)), int(rs.randint(1, 300))
+        span = 10.0 ** rs.uniform(-3, 0.7)
+        ang, rad = rs.uniform(0, 2 * np.pi), 2.0 + 10.0 ** rs.uniform(-6, 0.5) * rs.choice([1.0, 1.0, -0.05])
+        view = (rad * np.cos(ang) - rs.uniform(0, span), rad * np.sin(ang) - rs.uniform(0, span), span, span * rs.uniform(0.2, 2.0), w, h)
+        col0, row0 = int(rs.randint(0, w)), int(rs.randint(0, h))
+        window = (col0, row0, int(rs.randint(1, w - col0 + 1)), int(rs.randint(1, h - row0 + 1)))
+        for f32 in (False, True):
+            if outside(view, window, f32):
+                hits += 1
+                c, _, _ = oracle.view(*view[:4], w, h, 500, window=window, want_bytes=False, precision="f32" if f32 else "f64")
+                assert (c == 1).all(), (view, window, f32)
+    assert hits > 40, hits
