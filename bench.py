@@ -107,7 +107,12 @@ DEFAULT_STEPS = {"cfg1": (400, 50), "cfg2": (400, 50), "chunk_l1": (400, 50), "i
                  "cfg3": (20, 3), "cfg4": (3, 1), "cfg5": (40, 5)}
 # CPU baseline sample: every `stride`-th 8-row band, sized for ~10-30 CPU-seconds on >= 64 host threads
 CPU_SAMPLE_STRIDE = {"cfg4": 256}
-PMC_SUMMARIES = [("r04", "cfg2_default_pmc_summary.json"), ("r03", "cfg2_default_pmc_summary.json"), ("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
+# Short strict legs of the other single-GPU BASELINE configs inside the default `python bench.py` line (object `configs`;
+# VERDICT r4 item 2): name -> (workload, window (col0, row0, ncols, nrows) | None, timed launches, warm-up launches)
+EXTRA_CONFIGS = {"cfg3": ("cfg3", None, 2, 1), "cfg5": ("cfg5", None, 3, 1), "chunk_l1": ("chunk_l1", None, 20, 5),
+                 "cfg4_band": ("cfg4", (0, 7680, 16384, 1024), 2, 1)}
+GOLDEN_OUTPUTS = os.path.join(ROOT, "tests", "golden", "bench_outputs.json")   # made by tests/golden/make_bench_golden.py
+PMC_SUMMARIES = [("r05", "cfg2_default_pmc_summary.json"), ("r04", "cfg2_default_pmc_summary.json"), ("r03", "cfg2_default_pmc_summary.json"), ("r02", "cfg2_default_pmc_summary.json"), ("r01", "cfg2_default_pmc_summary.json")]
 
 
 def parse_args(argv=None):
@@ -304,6 +309,91 @@ def pmc_traffic(workload, kernel):
     return None, why
 
 
+def golden_outputs():
+    try:
+        with open(GOLDEN_OUTPUTS) as f:
+            return json.load(f)
+    except Exception:   # noqa: BLE001 -- a missing fixture is reported as "not verified", never fatal
+        return {}
+
+
+def verify_output(name, d_counts, pixel_iterations, never_pixels, view, mrd, precision, window=None):
+    """Pin a timed output inside this very run: sha256 of the int32 counts the launches wrote (one D2H) against the CPU
+    oracle's (tests/golden/bench_outputs.json, made by tests/golden/make_bench_golden.py), plus the two totals."""
+    import hashlib
+    g = golden_outputs().get(name)
+    if g is None:
+        return {"verified": None, "why": f"no golden entry '{name}' in tests/golden/bench_outputs.json"}
+    same_job = (list(g["view"]) == [view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height]
+                and g["mrd"] == mrd and g["precision"] == precision
+                and (tuple(g["window"]) if g["window"] else None) == (tuple(window) if window else None))
+    if not same_job:
+        return {"verified": None, "why": f"golden entry '{name}' describes another view / mrd / precision"}
+    digest = hashlib.sha256(d_counts.cpu().numpy().data).hexdigest()
+    ok = digest == g["counts_sha256"] and int(pixel_iterations) == g["pixel_iterations"] and int(never_pixels) == g["never_pixels"]
+    return {"verified": bool(ok), "counts_sha256": digest, "sha256_matches": digest == g["counts_sha256"],
+            "pixel_iterations_match": int(pixel_iterations) == g["pixel_iterations"],
+            "never_pixels_match": int(never_pixels) == g["never_pixels"],
+            "golden": f"tests/golden/bench_outputs.json['{name}'] (CPU oracle, {g['oracle']})"}
+
+
+def extra_configs(dev, torch, gpu_index, device_info):
+    """Short strict legs (cycle test off, library defaults otherwise) of the other single-GPU BASELINE configs, so that the
+    one command the driver times shows every one of them: per config `value`, `ms_per_step`, `roofline.frac` and
+    `output_verified` (the timed launches' own buffer against the oracle's hash).  Not part of the headline `value`."""
+    from distributedmandelbrot_amd import View
+    out = {}
+    stream = torch.cuda.current_stream()
+    for name, (wl, window, steps, warm) in EXTRA_CONFIGS.items():
+        try:
+            sr, si, rng, width, height, mrd, desc = WORKLOADS[wl]
+            precision = DEFAULT_PRECISION.get(wl, "f64")
+            smooth = wl in SMOOTH_WORKLOADS
+            view = View(sr, si, rng, rng, width, height)
+            col0, row0, ncols, nrows = window if window else (0, 0, width, height)
+            npx = ncols * nrows
+            d_counts = torch.empty(npx, dtype=torch.int32, device=f"cuda:{gpu_index}")
+            d_smooth = torch.empty(npx, dtype=torch.float64, device=f"cuda:{gpu_index}") if smooth else None
+
+            def launch():
+                if smooth:
+                    dev.launch_view_smooth(view, mrd, d_smooth=d_smooth.data_ptr(), d_counts=d_counts.data_ptr(), stream=stream.cuda_stream)
+                else:
+                    dev.launch_view(view, mrd, window=window, d_counts=d_counts.data_ptr(), stream=stream.cuda_stream, precision=precision)
+
+            for _ in range(warm):
+                launch()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(steps):
+                launch()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            ev_ms = e0.elapsed_time(e1) / steps
+            st = dev.reduce_counts(d_counts.data_ptr(), npx, mrd, stream=stream.cuda_stream)
+            cus, mhz = device_info["compute_units"], device_info["clock_mhz"]
+            peak = cus * 4 * (16 if precision == "f64" else 32) * mhz * 1e6 * 2 / 1e12
+            achieved = FLOPS_PER_PIXEL_ITER * st.pixel_iterations / (ev_ms / 1e3) / 1e12
+            out[name] = {
+                "workload": desc + (f"; rows {row0}..{row0 + nrows - 1} of it as one launch" if window else "")
+                            + ("; int32 counts + float64 nu to resident HBM" if smooth else "; int32 counts to resident HBM"),
+                "dtype": precision, "cycle_test": "off (every iteration executed)", "steps": steps, "warmup": warm,
+                "value": st.pixel_iterations * steps / wall / 1e9, "unit": "G pixel-iterations/s", "ms_per_step": wall / steps * 1e3,
+                "pixel_iterations_per_step": st.pixel_iterations,
+                "roofline": {"bound": "fp64_valu" if precision == "f64" else "fp32_valu", "achieved": achieved, "peak": peak,
+                             "unit": "TFLOP/s", "frac": achieved / peak, "kernel_ms_avg": ev_ms,
+                             "basis": "one pair of HIP events on the launch stream around the timed launches, elapsed / K"},
+                "output_verified": verify_output(name, d_counts, st.pixel_iterations, st.never_pixels, view, mrd, precision, window),
+            }
+            del d_counts, d_smooth
+        except Exception as e:   # noqa: BLE001 -- reported, must not cost the headline
+            out[name] = {"error": repr(e)}
+    return out
+
+
 def end_to_end(dev, level=16, mrd=1024):
     """the tile rate INCLUDING quantise + statistics + D2H, reported beside the headline.  A whole
     level of the reference's pyramid (level n = n x n DataChunk tiles of [-2,2]^2, Distributer.cs:335-353 hands out
@@ -361,6 +451,17 @@ def end_to_end(dev, level=16, mrd=1024):
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    fake_env = os.environ.get("MBK_BENCH_FAKE") == "1"
+    if args.gpus > 1 and not args.oversubscribe and not fake_env:
+        # one line instead of N ranks dying one by one: more ranks than GPUs is never a scaling number
+        try:
+            from distributedmandelbrot_amd import device_count
+            visible = device_count()
+        except Exception as e:   # noqa: BLE001
+            raise SystemExit(f"bench.py: cannot count the GPUs ({e}); there is no CPU fallback")
+        if args.gpus > visible:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) visible on this node; one process per GPU is the "
+                             "contract -- add --oversubscribe to exercise the N > 1 path on fewer GPUs (functional test, not a scaling number)")
     if args.gpus > 1 and world == 1:
         raise SystemExit(self_launch(args))     # start our own N ranks; each comes back here with WORLD_SIZE = N
     if world != args.gpus:
@@ -481,6 +582,12 @@ def main():
         # periodic orbits retired early) is timed in the same run as the extra object "cycle_detection".
         if "cycle_detect" not in options:
             dev.set_option("cycle_detect", 0)
+        # MBK_OPT_XCD_BALANCE is opt-in since round 5 (library default 0: it helps solitary launches without the cycle test
+        # only, +0.7..1.2 %, i.e. this leg and nothing a worker runs).  The strict headline leg of the one-tile-per-step mode
+        # asks for it -- stated in config.xcd_balance -- and it is switched off again before every other leg.
+        xcd_for_headline = own_mode and "xcd_balance" not in options and not options.get("cycle_detect", 0)
+        if xcd_for_headline:
+            dev.set_option("xcd_balance", 1)
         for k, v in options.items():
             dev.set_option(k, v)
         device_info = dev.info()
@@ -638,6 +745,7 @@ def main():
     xcd_after_timed = dev.xcd_shares() if not fake and hasattr(dev, "xcd_shares") else None
 
     never = 0
+    verified = None
     if queue_mode:
         iters_per_step = sum(v[0] for v in per_tile.values())
         never = sum(v[1] for v in per_tile.values())
@@ -653,6 +761,12 @@ def main():
             sync()
         st = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
         iters_per_step, never = st.pixel_iterations, st.never_pixels
+        if own_mode and rank == 0 and args.workload in golden_outputs():
+            # the buffer the LAST TIMED launch wrote, against the CPU oracle's hash (VERDICT r4 missing 3)
+            try:
+                verified = verify_output(args.workload, d_counts_all[(turn[0] - 1) % nstreams], iters_per_step, never, view, mrd, args.precision)
+            except Exception as e:   # noqa: BLE001 -- reported, must not cost the headline
+                verified = {"verified": None, "why": repr(e)}
         region_events = bool(events) and len(events[0]) == 3
         if region_events:   # one pair around the K launches: the average; then an untimed pass with a pair per launch
             kernel_ms_region = events[0][0].elapsed_time(events[0][1]) / events[0][2]
@@ -665,6 +779,8 @@ def main():
         else:
             kernel_ms_region = None
             kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
+        if xcd_for_headline:
+            dev.set_option("xcd_balance", 0)     # the library default for every leg that follows
 
     # N > 1, strong-scaling modes: the SAME job on ONE GPU, timed in this very run.  N = 1 defaults
     # to one tile per step (`--shard own`: the contract's headline), N > 1 to the tile queue, whose single-GPU rate is
@@ -692,7 +808,7 @@ def main():
     # second leg (own mode, fp64/fp32 count kernels): the same K steps with the library's default cycle test.
     # A failure here must not cost the headline: errors are caught (the barriers stay unconditional, so the ranks
     # stay in step) and reported in config.cycle_leg_error instead of the cycle_detection object.
-    cyc_leg, cyc_err = None, None
+    cyc_leg, cyc_err, cyc_verified = None, None, None
     second_leg = not fake and own_mode and "cycle_detect" not in options and args.kernel in ("default", "group", "scan")
     if second_leg:
         try:
@@ -715,6 +831,9 @@ def main():
             if cyc_err is None:
                 st2 = dev.reduce_counts(d_counts_all[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream)
                 cyc_leg = (cyc_elapsed, st2.pixel_iterations == iters_per_step and st2.never_pixels == never)
+                if rank == 0 and verified is not None and verified.get("verified") is not None:
+                    cyc_verified = verify_output(args.workload, d_counts_all[(turn[0] - 1) % nstreams], st2.pixel_iterations, st2.never_pixels,
+                                                 view, mrd, args.precision)
             dev.set_option("cycle_detect", 0)
         except Exception as e:   # noqa: BLE001
             cyc_err, cyc_leg = repr(e), None
@@ -790,6 +909,10 @@ def main():
                "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz,
                "cycle_leg_error": cyc_err,
                "occupancy_api_wg_per_cu": device_info.get("scan_occupancy"),
+               "xcd_balance": ("1 for this leg only, set by bench.py: MBK_OPT_XCD_BALANCE is opt-in (library default 0) -- it follows "
+                               "solitary launches without the cycle test, i.e. this leg; every other leg of this line and every worker "
+                               "path runs the even deal" if (not fake and xcd_for_headline) else
+                               (f"{options['xcd_balance']} (--opt)" if "xcd_balance" in options else "0 (library default)")),
                "xcd_shares": xcd_after_timed,
                "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                            ("bench.py self-launch" if "MBK_BENCH_RUN_ID" in os.environ else "single process"),
@@ -848,6 +971,9 @@ def main():
                 "hbm_GBps": out_bytes / avg_kernel_s / 1e9,
             },
         }
+        if verified is not None:
+            rec["output_verified"] = dict(verified, what="sha256 of the int32 counts the last timed launch wrote (one D2H after the timed "
+                                                         "region) and the two totals, against the CPU oracle's")
         if isinstance(solo, float):
             solo_value = iters_all * args.steps / solo / 1e9
             rec["single_gpu_same_job"] = {
@@ -870,6 +996,7 @@ def main():
                 "ms_per_step": cyc_leg[0] / args.steps * 1e3,
                 "speedup_vs_strict": elapsed_max / cyc_leg[0],
                 "same_pixel_iterations_and_never_count": bool(cyc_leg[1]),
+                "output_verified": cyc_verified,
             }
         if (world == 1 and own_mode and not fake and not args.no_extras and args.workload == "cfg2" and not smooth
                 and args.precision == "f64" and args.kernel == "default" and not options):
@@ -905,6 +1032,11 @@ def main():
             finally:
                 dev.set_option("cycle_detect", options.get("cycle_detect", 0))
             rec["queue_job"] = queue_job_single(args, rec["value"])
+            try:
+                dev.set_option("cycle_detect", 0)
+                rec["configs"] = extra_configs(dev, torch, gpu_index, device_info)
+            except Exception as e:   # noqa: BLE001
+                rec["configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not fake:
             rec["cpu_baseline"] = cpu_baseline(args.workload, workload, args.precision)
         elif world == 1 and fake:

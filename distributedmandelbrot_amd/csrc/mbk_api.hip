@@ -198,6 +198,43 @@ static uint32_t coprime_multiplier(uint32_t n)
     }
 }
 
+// Does a sample k in [k0, k0 + cnt) of the axis have 0 < |value| < 2^-900 (binary32: 2^-100 after the cast)?  Round 1-4
+// looked at every sample (4 096 per DataChunk, twice per submitted tile: 10 us of host time where an all-exterior tile costs
+// the GPU 25).  The samples before the pinned last one are a monotonic sequence -- k * step is monotonic in k, and so are the
+// roundings, the addition of `start` and the cast to float -- so the values nearest to zero sit at the sign change: two
+// binary searches find the last sample below zero and the first above it.  (tests: mbk_view_needs_literal_doubling against
+// the scan of every sample.)
+static bool axis_has_tiny_nonzero(const Axis &a, uint32_t k0, uint32_t cnt, bool f32)
+{
+    const double thr = f32 ? 0x1p-100 : kSafeImagMin;
+    auto value = [&](uint32_t k) { const double y = axis_value_host(a, k); return f32 ? (double)(float)y : y; };
+    auto tiny = [&](double y) { return y != 0.0 && std::fabs(y) < thr; };
+    if (cnt == 0) return false;
+    uint32_t end = k0 + cnt;                    // (k0 + cnt <= a.n: the caller checked the window)
+    if (a.n >= 1u && end == a.n) {              // the pinned last sample is not part of the monotonic sequence
+        if (tiny(value(a.n - 1u))) return true;
+        if (--end == k0) return false;
+    }
+    const double first = value(k0), last = value(end - 1u);
+    if (tiny(first) || tiny(last)) return true;
+    if ((first > 0.0 && last > 0.0) || (first < 0.0 && last < 0.0) || first == last) return false;   // no sign change inside
+    const double s = last > first ? 1.0 : -1.0;   // s * value(k) is non-decreasing
+    auto lower = [&](bool strict) {               // first k in [k0, end) with s * value(k) >= 0 (strict: > 0); end if none
+        uint32_t lo = k0, hi = end;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            const double y = s * value(mid);
+            if (strict ? y > 0.0 : y >= 0.0) hi = mid;
+            else lo = mid + 1u;
+        }
+        return lo;
+    };
+    const uint32_t ge = lower(false), gt = lower(true);
+    if (ge > k0 && tiny(value(ge - 1u))) return true;     // the last sample on the far side of zero
+    if (gt < end && tiny(value(gt))) return true;         // the first one on the near side
+    return false;
+}
+
 static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling, bool f32 = false)
 {
     if (!v) return fail(ctx, MBK_ERR_INVALID, "view is NULL");
@@ -214,15 +251,7 @@ static int validate_view(mbk_ctx *ctx, const mbk_view *v, bool *safe_doubling, b
         if (!std::isfinite(x) || std::fabs(x) > max_coord)
             return fail(ctx, MBK_ERR_INVALID, f32 ? "view coordinates must be finite and |x| <= 2^60 (fp32)"
                                                   : "view coordinates must be finite and |x| <= 2^500");
-    bool safe = false;
-    const Axis im = make_axis(v->start_i, v->range_i, v->height);
-    for (uint32_t r = 0; r < v->nrows && !safe; ++r) {
-        const double ci64 = axis_value_host(im, v->row0 + r);
-        // the same argument in binary32: a subnormal product matters only below 2^-126 * 2^24
-        const double ci = f32 ? std::fabs((double)(float)ci64) : std::fabs(ci64);
-        if (ci != 0.0 && ci < (f32 ? 0x1p-100 : kSafeImagMin)) safe = true;
-    }
-    *safe_doubling = safe;
+    *safe_doubling = axis_has_tiny_nonzero(make_axis(v->start_i, v->range_i, v->height), v->row0, v->nrows, f32);
     return MBK_OK;
 }
 
@@ -391,9 +420,10 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                 sc->done_valid[k] = false;
             }
             sc->order_cap = 0;
-            // list | 3 counters | middle-class list (classify_blocks_kernel) | XCD shares of the units kernel (64-byte aligned)
+            // list | 3 counters | middle-class list (classify_blocks_kernel) | 2 counters, the units kernel's plan (64-byte aligned)
+            // | its settled H entries (mbk_units.h: units_settled_base)
             for (int k = 0; k < 2; ++k)
-                MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], (2u * (size_t)grid.x + 3u + 16u + mbk::kPlanWords) * sizeof(uint32_t)));
+                MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], mbk::units_list_words(grid.x) * sizeof(uint32_t)));
             sc->order_cap = grid.x;
         }
         // Pre-pass of THIS launch on the aux stream: it depends on the window only, not on anything the caller's
@@ -409,10 +439,13 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
         if (units) {
-            // MBK_OPT_M_LATE = s > 0: M blocks whose centre pixel escapes at step >= s open the dispatch order (mbk_units.h)
-            MBK_HIP(ctx, hipMemsetAsync(ord + 2u * (size_t)grid.x + 3u, 0, sizeof(uint32_t), pre));   // count of late M entries
+            // MBK_OPT_M_LATE = s > 0: M blocks whose centre pixel escapes at step >= s open the dispatch order; MBK_OPT_H_SETTLED
+            // = k > 0 (with the cycle test only): H blocks whose probe orbit is within 10^-k of settled close the front list
+            const uint32_t hs = cyc ? ctx->opt[MBK_OPT_H_SETTLED] : 0u;
+            const double settle_thr = hs ? std::pow(10.0, -(double)hs) : 0.0;
+            MBK_HIP(ctx, hipMemsetAsync(ord + 2u * (size_t)grid.x + 3u, 0, 2 * sizeof(uint32_t), pre));   // counts: late M, settled H
             hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a, grid.x,
-                               (int32_t)probe_steps, ord, cursors, (int32_t)ctx->opt[MBK_OPT_M_LATE]);
+                               (int32_t)probe_steps, ord, cursors, (int32_t)ctx->opt[MBK_OPT_M_LATE], settle_thr);
             // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
             // stream, 2 a fixed uneven deal (tests)
             // (1 applies to the strict loops only: with the cycle test a launch ends with the drain of its boundary blocks, which
@@ -439,7 +472,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                 used.f[x] = (float)f[x];
             }
             shares_from_fractions(f, w.cum);
-            a.plan = ord + ((2u * (size_t)grid.x + 3u + 15u) & ~(size_t)15u);
+            a.plan = ord + ((2u * (size_t)grid.x + 5u + 15u) & ~(size_t)15u);   // (ends below units_settled_base: + 16 + 40 <= + 64)
             a.stamps = balance == 1u ? sc->h_stamps + (size_t)(seq % kStampSlots) * mbk::kStampWords : nullptr;
             a.stamp_tag = seq & 0xffffu;
             hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)cursors,
@@ -1010,7 +1043,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u};
+        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1368,6 +1401,16 @@ int mbk_view_submit(mbk_ctx *ctx, int slot, const mbk_view *view, uint32_t mrd, 
     return submit_view(ctx, ctx->s[slot], view, mrd, flags, h_counts, h_bytes);
 }
 
+int mbk_view_needs_literal_doubling(const mbk_view *view, uint32_t flags, int *literal)
+{
+    if (!view || !literal) return fail(nullptr, MBK_ERR_INVALID, "NULL argument");
+    bool safe = false;
+    const int rc = validate_view(nullptr, view, &safe, (flags & MBK_PRECISION_F32) != 0);
+    if (rc != MBK_OK) return rc;
+    *literal = safe ? 1 : 0;
+    return MBK_OK;
+}
+
 int mbk_view_outside_circle(const mbk_view *view, uint32_t flags, int *outside)
 {
     if (!view || !outside) return fail(nullptr, MBK_ERR_INVALID, "NULL argument");
@@ -1528,6 +1571,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_UNITS_MIN_LIGHT: ok = value <= 65536u; break;
         case MBK_OPT_XCD_BALANCE: ok = value <= 2u; break;
         case MBK_OPT_M_LATE: ok = value <= 65536u; break;
+        case MBK_OPT_H_SETTLED: ok = value <= 30u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");

@@ -37,7 +37,13 @@ namespace mbk {
 // the back, order[n .. n+3) the counters (H, V units, M), order[n+3 .. 2n+3) the M entries.  H / M entry: (block row << 16)
 // | block column.  V unit: (block row << 16) | (first block column / 8) << 8 | mask of the V blocks among its 8 columns.
 // Needs blocks_x % 8 == 0 (a unit never wraps a row), blocks_x <= 2048, block rows < 65536 (the host checks).
-// With m_late > 0 the "late" M entries sit at the back of the M region (order[2n+2] downwards, count at order[2n+3]).
+// With m_late > 0 the "late" M entries sit at the back of the M region (order[2n+2] downwards, count at order[2n+3]); with
+// settle_thr > 0 the settled H entries have a region of their own (order[units_settled_base(n) ..), count at order[2n+4]).
+// The dispatch order is: late M, H (unsettled), settled H | M, V units -- the part before the bar is the "front list" that the
+// XCD shares deal unevenly.
+__host__ __device__ inline size_t units_settled_base(size_t n) { return 2u * n + 64u; }   // (the plan sits in between)
+__host__ __device__ inline size_t units_list_words(size_t n) { return 3u * n + 64u; }
+
 //
 // M LATE (round 5).  A block with a pixel that never escapes runs all mrd - 1 steps, and from its start to its end it needs
 // >= 6 125 dependent-issue instructions ~ 21 us however empty the chip is (a lone wave issues one fp64 instruction per ~8
@@ -49,14 +55,48 @@ namespace mbk {
 // >= 8 (exact counts: 209 of 209, 175 of 175; >= 12 holds 207 / 173), so the probe sorts them out for free: M entries whose
 // centre escapes at step >= m_late are filed apart and dispatched FIRST, before H; the rest of M and the V units stay behind
 // H as the filler of its drain.
-__global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
-                                                              uint32_t *order, uint32_t *counters, int32_t m_late)
+//
+// H SETTLED (round 5, with the cycle test only).  With the cycle test the H class is no longer uniform: a block whose orbits
+// have settled on their attracting cycle retires within a few checks (cfg2: 27 669 of 47 683 H blocks, 194 steps on
+// average), one whose orbits have not runs (nearly) all mrd - 1 steps (20 014 blocks, 772 on average, 98.5 % of those that run
+// >= 900).  H is dispatched in image order, so the last H blocks to start -- at 8 waves per SIMD the youngest wave of a SIMD
+// gets what its elders leave: 50-65 us for a long block -- ended the launch once the late M blocks were out of the way
+// (profiles/r05/units_trace_*.txt).  The probe sorts them at no cost: delta = min over p in {1..6, 8} of
+// |z_last - z_(last-p)|^2 of the centre pixel after its 32 steps; H blocks with delta <= settle_thr are filed apart and
+// dispatched behind the unsettled ones.  (On its own -- without M late -- this order LOST 1.8 % on cfg2: profiles/r05/README.)
+__device__ __forceinline__ int32_t probe_settling(double cr, double ci, int32_t cap, double *delta)
 {
-    __shared__ uint32_t s_cnt[4][16], s_base[4];
+    double zr = cr, zi = ci, sr[7], si[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sr[k] = si[k] = 1e300;
+    for (int32_t n = 1; n < cap; ++n) {
+        const double t = zr * zr - zi * zi;
+        zi = __builtin_fma(2.0, zr * zi, ci);
+        zr = t + cr;
+        if (zr * zr + zi * zi >= 4.0) { *delta = 1e300; return n; }
+        const int32_t back = cap - 1 - n;        // this state is z_(last - back)
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+            if (back == (k < 6 ? k + 1 : 8)) { sr[k] = zr; si[k] = zi; }
+    }
+    double d = 1e300;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double dr = zr - sr[k], di = zi - si[k], q = dr * dr + di * di;
+        d = q < d ? q : d;
+    }
+    *delta = d;
+    return 0;
+}
+
+__global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
+                                                              uint32_t *order, uint32_t *counters, int32_t m_late, double settle_thr)
+{
+    __shared__ uint32_t s_cnt[5][16], s_base[5];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const bool valid = r < nregions;
-    uint32_t cls = 4u;     // 0 H, 1 V, 2 M, 3 M late, 4 nothing
+    uint32_t cls = 5u;     // 0 H, 1 V, 2 M, 3 M late, 4 H settled, 5 nothing
     uint32_t by = 0, bx = 0;
     if (valid) {
         by = r / p.blocks_x;
@@ -66,23 +106,24 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
         lr = lr < p.nrows ? lr : p.nrows - 1u;
         const double cr = axis_value(p.re, p.col0 + lc), ci = axis_value(p.im, p.row0 + lr);
         const int32_t cap = p.mrd < probe_steps ? p.mrd : probe_steps;
-        const int32_t cnt = cap > 1 ? escape_count<true>(cr, ci, cap) : 1;
+        double delta = 1e300;
+        const int32_t cnt = cap > 1 ? (settle_thr > 0.0 ? probe_settling(cr, ci, cap, &delta) : escape_count<true>(cr, ci, cap)) : 1;
         const bool regular = bx < p.fast_bx_end && by < p.fast_by_end;   // the light path's coordinates are the regular formula
-        cls = cnt == 0 ? 0u : (cnt <= 3 && regular ? 1u : (m_late > 0 && cnt >= m_late ? 3u : 2u));
+        cls = cnt == 0 ? (delta <= settle_thr ? 4u : 0u) : (cnt <= 3 && regular ? 1u : (m_late > 0 && cnt >= m_late ? 3u : 2u));
     }
     // V blocks -> one unit per aligned group of 8 lanes (= 8 block columns of one row: blocks_x % 8 == 0 and the workgroup's
     // first region is a multiple of 8)
     const unsigned long long vmask = __ballot(cls == 1u);
     const uint32_t seg = (uint32_t)(vmask >> (lane & ~7u)) & 0xffu;
-    const bool emit[4] = {cls == 0u, (lane & 7u) == 0u && seg != 0u, cls == 2u, cls == 3u};
-    unsigned long long m[4];
+    const bool emit[5] = {cls == 0u, (lane & 7u) == 0u && seg != 0u, cls == 2u, cls == 3u, cls == 4u};
+    unsigned long long m[5];
 #pragma unroll
-    for (uint32_t k = 0; k < 4u; ++k) {
+    for (uint32_t k = 0; k < 5u; ++k) {
         m[k] = __ballot(emit[k]);
         if (lane == 0) s_cnt[k][wave] = (uint32_t)__popcll(m[k]);
     }
     __syncthreads();
-    if (threadIdx.x < 4u) {
+    if (threadIdx.x < 5u) {
         const uint32_t k = threadIdx.x, nw = (blockDim.x + 63u) >> 6;
         uint32_t t = 0;
         for (uint32_t w = 0; w < nw; ++w) {
@@ -90,7 +131,7 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
             s_cnt[k][w] = t;
             t += c;
         }
-        s_base[k] = t ? atomicAdd(k < 3u ? &counters[k] : &order[2u * nregions + 3u], t) : 0u;
+        s_base[k] = t ? atomicAdd(k < 3u ? &counters[k] : &order[2u * nregions + k], t) : 0u;   // [2n+3] late M, [2n+4] settled H
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -98,6 +139,7 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
     if (emit[1]) order[nregions - 1u - (s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(m[1] & below))] = (by << 16) | ((bx >> 3) << 8) | seg;
     if (emit[2]) order[nregions + 3u + s_base[2] + s_cnt[2][wave] + (uint32_t)__popcll(m[2] & below)] = (by << 16) | bx;
     if (emit[3]) order[2u * nregions + 2u - (s_base[3] + s_cnt[3][wave] + (uint32_t)__popcll(m[3] & below))] = (by << 16) | bx;
+    if (emit[4]) order[units_settled_base(nregions) + s_base[4] + s_cnt[4][wave] + (uint32_t)__popcll(m[4] & below)] = (by << 16) | bx;
 }
 
 // ---- Shares of the eight XCDs ------------------------------------------------------------------------------------------
@@ -114,14 +156,15 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
 constexpr uint32_t kStampTail = 8;                      // ids per XCD, from the end, that leave a time stamp
 constexpr uint32_t kStampWords = 8u + 8u * kStampTail;  // per launch: first id of every XCD, then the tails
 constexpr uint32_t kPlanWords = 40;  // [0] H entries [1] M entries [2] ids in all (8 per XCD round) [3] min h [4] min l
-                                     // [5] 1 = this launch leaves time stamps [6] late M entries: the first [6] of the [0] front entries
+                                     // [5] 1 = this launch leaves time stamps [6] late M entries: the first [6] of the [0] front
+                                     // entries [7] where the settled H entries begin in the front list
                                      // [8..16) h[x]  [16..24) l[x]  [24..32) H base[x]  [32..40) light base[x]
 struct XcdShares { uint32_t cum[8]; };   // H list: share of XCDs 0..x, in 2^-24 (cum[7] = 2^24)
 
 // (host and device: mbk_units_plan / mbk_units_lookup of the C ABI run the same lines for the CPU tests)
-// (n_h: the entries of the FRONT list = the n_ml late M entries, then the H entries; n_m: the other M entries)
+// (n_h: the entries of the FRONT list = the n_ml late M entries, the unsettled H entries, the n_hs settled ones; n_m: the other M)
 __host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const uint32_t *cum, uint32_t stamps, uint32_t *plan,
-                                           uint32_t n_ml = 0u)
+                                           uint32_t n_ml = 0u, uint32_t n_hs = 0u)
 {
     const uint32_t n_l = n_m + n_v, total = n_h + n_l;
     uint32_t h[8], l[8], prev = 0, slots = (total + 7u) >> 3;
@@ -142,7 +185,7 @@ __host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t 
         hmin = hmin < h[x] ? hmin : h[x];
         lmin = lmin < l[x] ? lmin : l[x];
     }
-    plan[0] = n_h; plan[1] = n_m; plan[2] = slots * 8u; plan[3] = hmin; plan[4] = lmin; plan[5] = stamps; plan[6] = n_ml < n_h ? n_ml : n_h; plan[7] = 0u;
+    plan[0] = n_h; plan[1] = n_m; plan[2] = slots * 8u; plan[3] = hmin; plan[4] = lmin; plan[5] = stamps; plan[6] = n_ml < n_h ? n_ml : n_h; plan[7] = n_hs < n_h ? n_h - n_hs : 0u;
     uint32_t hb = 8u * hmin, lb = 8u * lmin;   // the contiguous pieces start behind the evenly dealt part
     for (uint32_t x = 0; x < 8u; ++x) {
         plan[8u + x] = h[x];
@@ -168,29 +211,30 @@ __host__ __device__ __forceinline__ bool units_lookup(uint32_t u, uint32_t hmin,
 
 __global__ void units_plan_kernel(const uint32_t *counters, const uint32_t *late, XcdShares w, uint32_t stamps, uint32_t *plan)
 {
-    // (late = order + 2n + 3: the count of late M entries, which open the front list)
+    // (late = order + 2n + 3: the counts of late M entries, which open the front list, and of settled H entries, which end it)
     if (threadIdx.x == 0 && blockIdx.x == 0)
-        units_plan(counters[0] + late[0], counters[1], counters[2], w.cum, stamps, plan, late[0]);
+        units_plan(counters[0] + late[0] + late[1], counters[1], counters[2], w.cum, stamps, plan, late[0], late[1]);
 }
 
-// The ten words of the plan a workgroup of XCD x needs, with scalar loads issued together (scalar_load_u32's comment)
+// The eleven words of the plan a workgroup of XCD x needs, with scalar loads issued together (scalar_load_u32's comment)
 __device__ __forceinline__ void load_shares(const uint32_t *plan, uint32_t x, uint32_t &n_m, uint32_t &total, uint32_t &hmin,
-                                            uint32_t &lmin, uint32_t &stamps, uint32_t &n_ml, uint32_t &h_x, uint32_t &l_x,
+                                            uint32_t &lmin, uint32_t &stamps, uint32_t &n_ml, uint32_t &hs0, uint32_t &h_x, uint32_t &l_x,
                                             uint32_t &hbase_x, uint32_t &lbase_x)
 {
     const uint32_t *pl = plan, *px = plan + x;      // (kernel argument + workgroup id: scalar registers as they stand)
-    asm volatile("s_load_dword %0, %10, 0x4\n\t"
-                 "s_load_dword %1, %10, 0x8\n\t"
-                 "s_load_dword %2, %10, 0xc\n\t"
-                 "s_load_dword %3, %10, 0x10\n\t"
-                 "s_load_dword %4, %10, 0x14\n\t"
-                 "s_load_dword %5, %10, 0x18\n\t"
-                 "s_load_dword %6, %11, 0x20\n\t"
-                 "s_load_dword %7, %11, 0x40\n\t"
-                 "s_load_dword %8, %11, 0x60\n\t"
-                 "s_load_dword %9, %11, 0x80\n\t"
+    asm volatile("s_load_dword %0, %11, 0x4\n\t"
+                 "s_load_dword %1, %11, 0x8\n\t"
+                 "s_load_dword %2, %11, 0xc\n\t"
+                 "s_load_dword %3, %11, 0x10\n\t"
+                 "s_load_dword %4, %11, 0x14\n\t"
+                 "s_load_dword %5, %11, 0x18\n\t"
+                 "s_load_dword %6, %11, 0x1c\n\t"
+                 "s_load_dword %7, %12, 0x20\n\t"
+                 "s_load_dword %8, %12, 0x40\n\t"
+                 "s_load_dword %9, %12, 0x60\n\t"
+                 "s_load_dword %10, %12, 0x80\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(n_m), "=&s"(total), "=&s"(hmin), "=&s"(lmin), "=&s"(stamps), "=&s"(n_ml), "=&s"(h_x), "=&s"(l_x),
+                 : "=&s"(n_m), "=&s"(total), "=&s"(hmin), "=&s"(lmin), "=&s"(stamps), "=&s"(n_ml), "=&s"(hs0), "=&s"(h_x), "=&s"(l_x),
                    "=&s"(hbase_x), "=&s"(lbase_x)
                  : "s"(pl), "s"(px)
                  : "memory");
@@ -249,8 +293,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (uint32_t u = blockIdx.x;; u += p.unit_stride) {
         // (the shares are read anew on every trip -- a second trip is rare -- so that nothing of them stays in scalar
         // registers across a block)
-        uint32_t n_m, total, hmin, lmin, stamps, n_ml, h_x, l_x, hbase_x, lbase_x;
-        load_shares(args.plan, x, n_m, total, hmin, lmin, stamps, n_ml, h_x, l_x, hbase_x, lbase_x);
+        uint32_t n_m, total, hmin, lmin, stamps, n_ml, hs0, h_x, l_x, hbase_x, lbase_x;
+        load_shares(args.plan, x, n_m, total, hmin, lmin, stamps, n_ml, hs0, h_x, l_x, hbase_x, lbase_x);
         if (stamps && u < p.unit_stride) {
             // first trip: the first workgroup of every XCD and its last kStampTail tell the host when they started
             const uint32_t j0 = u >> 3, slots = total >> 3;
@@ -262,9 +306,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         uint32_t i;    // index into the H list / the light list (M entries, then V units)
         if (!units_lookup(u, hmin, lmin, h_x, l_x, hbase_x, lbase_x, is_h, i)) break;
         if (is_h || i < n_m) {
-            // (front entry i: the late M entries from the back of the M region, then the H list)
+            // (front entry i: the late M entries from the back of the M region, the H list, the settled H entries from their region)
             const bool late = is_h && i < n_ml;
-            const uint32_t e = scalar_load_u32(p.order, is_h ? (late ? 2u * n + 2u - i : i - n_ml) : n + 3u + i);
+            const uint32_t e = scalar_load_u32(p.order, is_h ? (late ? 2u * n + 2u - i : (i < hs0 ? i - n_ml : (uint32_t)units_settled_base(n) + (i - hs0)))
+                                                              : n + 3u + i);
             const uint32_t by = e >> 16, bx = e & 0xffffu;
             const int32_t c = block_pixel<T, true, kGroup, kCycle>(p, bx * 8u, by * 8u, lx, ly, kGroup >= 16 && is_h && !late,
                                                                    bx < p.fast_bx_end && by < p.fast_by_end);

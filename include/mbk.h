@@ -217,6 +217,10 @@ int mbk_wait(mbk_ctx *ctx, int slot, mbk_stats *stats);
  * of the window has |c|^2 >= 4 (1 + m), m = 1e-8 (1e-4 with MBK_PRECISION_F32 in flags) -- then calc_mb_value returns 1
  * for every pixel when mrd >= 2 (WorkerCUDA.py:54-63: z1 = c^2 + c, |z1| >= |c| (|c| - 1) > 2).  For the CPU tests. */
 int mbk_view_outside_circle(const mbk_view *view, uint32_t flags, int *outside);
+/* Likewise: *literal = 1 when the window holds a row whose imaginary coordinate is non-zero but below 2^-900 (2^-100 in
+ * binary32) -- the one case in which fma(2, zr * zi, ci) differs from the reference's fl(fl((2 * zr) * zi) + ci) (a
+ * subnormal product), so that the launch takes the kernels with the literal form.  For the CPU tests. */
+int mbk_view_needs_literal_doubling(const mbk_view *view, uint32_t flags, int *literal);
 /* The same for a generic view / window (the multi-GPU shard unit is a row band of a view): enqueue on
  * `slot`, results land in h_counts / h_bytes (either may be NULL according to flags) after mbk_wait. */
 int mbk_view_submit(mbk_ctx *ctx, int slot, const mbk_view *view, uint32_t mrd, uint32_t flags,
@@ -307,6 +311,11 @@ enum mbk_option {
                               hold a never-escaping pixel run as long as an interior block and used to start a few microseconds
                               before the dispatchers ran dry (csrc/mbk_units.h): 0 (off: H, M, V), 4..31 [8].  Changes when a
                               block is computed, never what is stored */
+    MBK_OPT_H_SETTLED,     /* order 3, with the cycle test only: interior blocks whose probe orbit is within 10^-k of settled (min over p of
+                              |z_32 - z_(32-p)|^2 of the centre pixel) retire within a few checks, the others run (nearly) all
+                              steps; the settled ones are dispatched behind the others, so that the last interior blocks to
+                              start are short ones: 0 (one list), k = 1..30 [6].  Measured only together with M late
+                              (profiles/r05).  Changes when a block is computed, never what is stored */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

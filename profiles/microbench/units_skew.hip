@@ -146,7 +146,7 @@ int main(int argc, char **argv)
     const uint32_t nblocks = a.blocks_x * (H / 8);
     CHECK(hipMalloc(&a.counts, (size_t)W * H * 4));
     int32_t *ref_counts; CHECK(hipMalloc(&ref_counts, (size_t)W * H * 4));
-    uint32_t *ord; CHECK(hipMalloc(&ord, (2 * (size_t)nblocks + 3) * 4));
+    uint32_t *ord; CHECK(hipMalloc(&ord, mbk::units_list_words(nblocks) * 4));
     a.order = ord; a.ngrid = nblocks; a.unit_stride = nblocks;
     unsigned long long *stamps; CHECK(hipHostMalloc(&stamps, (8 + 8 * kTail) * 8, hipHostMallocDefault));
     unsigned long long *ends; CHECK(hipMalloc(&ends, (size_t)nblocks * 8));
@@ -155,7 +155,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     uint32_t cnt[3] = {0, 0, 0};
     CHECK(hipMemset(ord + nblocks, 0, 12));
-    mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, 0);
+    mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, 0, 0.0);
     CHECK(hipMemcpy(cnt, ord + nblocks, 12, hipMemcpyDeviceToHost));
     const uint32_t n_h = cnt[0], n_v = cnt[1], n_m = cnt[2];
     printf("%s: H %u, V units %u, M %u; controller gain %.2f, rotation %u, cycle test %d, signal %s\n", wl.c_str(), n_h, n_v, n_m, gain, rot, (int)cyc,

@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/units_trace profiles/microbench/units_trace.hip
 //   /tmp/units_trace cfg2 gpurun_out/units_trace_cfg2.bin && python scripts/analyze_units_trace.py gpurun_out/units_trace_cfg2.bin
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,8 +20,8 @@
 
 struct Rec { unsigned long long t0, t1; unsigned hw, xcc, unit, cls; };
 
-// Dispatch order: [late M entries (round 5, MBK_OPT_M_LATE: from the back of the M region)] [H] [M] [V units]; class codes in the
-// record: 0 H, 1 M, 2 V, 4 late M.
+// Dispatch order: [late M entries (round 5, MBK_OPT_M_LATE: from the back of the M region)] [H] [settled H (MBK_OPT_H_SETTLED: a
+// region of their own)] [M] [V units]; class codes in the record: 0 H, 1 M, 2 V, 4 late M, 5 settled H.
 template <bool kCycle>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void traced_units_kernel(mbk::TileArgs args, uint32_t qtab, Rec *rec)
 {
@@ -30,18 +31,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const uint32_t lane = threadIdx.x, lx = lane & 7u, ly = lane >> 3;
     const uint32_t n = p.ngrid;
     const uint32_t n_h = mbk::uniform_u32(p.order[n]), n_v = mbk::uniform_u32(p.order[n + 1u]), n_m = mbk::uniform_u32(p.order[n + 2u]);
-    const uint32_t n_ml = mbk::uniform_u32(p.order[2u * n + 3u]);
+    const uint32_t n_ml = mbk::uniform_u32(p.order[2u * n + 3u]), n_hs = mbk::uniform_u32(p.order[2u * n + 4u]);
     const uint32_t u = blockIdx.x;
     uint32_t cls = 3u;
-    if (u < n_ml + n_h + n_m) {
-        const bool late = u < n_ml, is_h = !late && u < n_ml + n_h;
-        cls = late ? 4u : is_h ? 0u : 1u;
-        const uint32_t e = mbk::uniform_u32(late ? p.order[2u * n + 2u - u] : is_h ? p.order[u - n_ml] : p.order[n + 3u + (u - n_ml - n_h)]);
+    if (u < n_ml + n_h + n_hs + n_m) {
+        const bool late = u < n_ml, is_hu = !late && u < n_ml + n_h, is_hs = !late && !is_hu && u < n_ml + n_h + n_hs;
+        cls = late ? 4u : is_hu ? 0u : is_hs ? 5u : 1u;
+        const uint32_t e = mbk::uniform_u32(late ? p.order[2u * n + 2u - u] : is_hu ? p.order[u - n_ml]
+                                            : is_hs ? p.order[mbk::units_settled_base(n) + (u - n_ml - n_h)] : p.order[n + 3u + (u - n_ml - n_h - n_hs)]);
         const uint32_t by = e >> 16, bx = e & 0xffffu;
-        mbk::block_pixel<double, true, 16, kCycle>(p, bx * 8u, by * 8u, lx, ly, is_h, bx < p.fast_bx_end && by < p.fast_by_end);
-    } else if (u < n_ml + n_h + n_m + n_v) {
+        mbk::block_pixel<double, true, 16, kCycle>(p, bx * 8u, by * 8u, lx, ly, is_hu || is_hs, bx < p.fast_bx_end && by < p.fast_by_end);
+    } else if (u < n_ml + n_h + n_hs + n_m + n_v) {
         cls = 2u;
-        const uint32_t v = mbk::uniform_u32(p.order[n - 1u - (u - n_ml - n_h - n_m)]);
+        const uint32_t v = mbk::uniform_u32(p.order[n - 1u - (u - n_ml - n_h - n_hs - n_m)]);
         const uint32_t by = v >> 16, bx0 = ((v >> 8) & 0xffu) << 3, mask = v & 0xffu;
         const double ci = (double)(p.row0 + by * 8u + ly) * p.im.step + p.im.start, b0 = ci * ci;
         const size_t elem0 = (size_t)(by * 8u + p.out_row0) * p.out_pitch + bx0 * 8u + p.out_col0;
@@ -70,6 +72,8 @@ int main(int argc, char **argv)
     const char *out = argc > 2 ? argv[2] : "gpurun_out/units_trace.bin";
     const bool cyc = argc > 3 && atoi(argv[3]) != 0;          // the library's default: the cycle test
     const int m_late = argc > 4 ? atoi(argv[4]) : 0;          // MBK_OPT_M_LATE
+    const int h_settled = argc > 5 ? atoi(argv[5]) : 0;       // MBK_OPT_H_SETTLED (k: threshold 10^-k)
+    const double settle_thr = h_settled ? pow(10.0, -(double)h_settled) : 0.0;
     const uint32_t W = 4096, H = 4096, mrd = 1000;
     mbk::TileArgs a; memset(&a, 0, sizeof(a));
     auto mk = [](double start, double range, uint32_t n) { mbk::Axis x; memset(&x, 0, sizeof(x)); x.start = start; x.n = n;
@@ -84,18 +88,19 @@ int main(int argc, char **argv)
     a.perm_mul = 1;
     const uint32_t nblocks = a.blocks_x * (H / 8);
     CHECK(hipMalloc(&a.counts, (size_t)W * H * 4));
-    uint32_t *ord; CHECK(hipMalloc(&ord, (2 * (size_t)nblocks + 4) * 4));
+    uint32_t *ord; CHECK(hipMalloc(&ord, mbk::units_list_words(nblocks) * 4));
     a.order = ord; a.ngrid = nblocks; a.unit_stride = nblocks;
     Rec *d; CHECK(hipMalloc(&d, (size_t)nblocks * sizeof(Rec)));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    uint32_t cnt[3] = {0, 0, 0}, n_ml = 0;
+    uint32_t cnt[3] = {0, 0, 0}, n_ml = 0, n_hs = 0;
     for (int rep = 0; rep < 160; ++rep) {      // (the clock needs ~100 launches to settle; the last launch is the one recorded)
         CHECK(hipMemset(ord + nblocks, 0, 12));
-        CHECK(hipMemset(ord + 2 * (size_t)nblocks + 3, 0, 4));
-        mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, m_late);
+        CHECK(hipMemset(ord + 2 * (size_t)nblocks + 3, 0, 8));
+        mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, m_late, settle_thr);
         CHECK(hipMemcpy(cnt, ord + nblocks, 12, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(&n_ml, ord + 2 * (size_t)nblocks + 3, 4, hipMemcpyDeviceToHost));
-        const uint32_t total = cnt[0] + cnt[1] + cnt[2] + n_ml;
+        CHECK(hipMemcpy(&n_hs, ord + 2 * (size_t)nblocks + 4, 4, hipMemcpyDeviceToHost));
+        const uint32_t total = cnt[0] + cnt[1] + cnt[2] + n_ml + n_hs;
         CHECK(hipMemset(d, 0, (size_t)nblocks * sizeof(Rec)));
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
@@ -104,9 +109,9 @@ int main(int argc, char **argv)
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep >= 156) printf("%s rep %d (cycle test %d, m_late %d): late M %u, H %u, V units %u, M %u -> %u workgroups, %.3f ms\n", wl.c_str(), rep, (int)cyc, m_late, n_ml, cnt[0], cnt[1], cnt[2], total, ms);
+        if (rep >= 156) printf("%s rep %d (cycle test %d, m_late %d, h_settled %d): late M %u, H %u, settled H %u, V units %u, M %u -> %u workgroups, %.3f ms\n", wl.c_str(), rep, (int)cyc, m_late, h_settled, n_ml, cnt[0], n_hs, cnt[1], cnt[2], total, ms);
     }
-    const uint32_t total = cnt[0] + cnt[1] + cnt[2] + n_ml;
+    const uint32_t total = cnt[0] + cnt[1] + cnt[2] + n_ml + n_hs;
     std::vector<Rec> h(total);
     CHECK(hipMemcpy(h.data(), d, (size_t)total * sizeof(Rec), hipMemcpyDeviceToHost));
     FILE *f = fopen(out, "wb"); fwrite(h.data(), sizeof(Rec), total, f); fclose(f);

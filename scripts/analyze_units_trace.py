@@ -30,7 +30,7 @@ for path in sys.argv[1:]:
     ids, inv = np.unique(sid, return_inverse=True)
     cls = r["cls"]
     print(f"{path}: {len(r)} workgroups on {len(ids)} SIMDs, {len(np.unique(xcc))} XCCs; launch {T:.1f} us (first start to last end)")
-    for c, name in ((4, "late M"), (0, "H"), (1, "M"), (2, "V")):
+    for c, name in ((4, "late M"), (0, "H"), (5, "H set."), (1, "M"), (2, "V")):
         m = cls == c
         if m.any():
             d = t1[m] - t0[m]
@@ -42,7 +42,7 @@ for path in sys.argv[1:]:
     width = T / nb
     occ = np.zeros((len(ids), nb))
     occ_h = np.zeros((len(ids), nb))
-    for arr, sel in ((occ, np.ones(len(r), bool)), (occ_h, cls == 0)):
+    for arr, sel in ((occ, np.ones(len(r), bool)), (occ_h, (cls == 0) | (cls == 5))):
         a = t0[sel]
         b = t1[sel]
         s = inv[sel]
@@ -78,11 +78,11 @@ for path in sys.argv[1:]:
         print(f"    XCC {x}: last wave end mean {last[xid == x].mean():7.1f} max {last[xid == x].max():7.1f};  H workgroups {int(((cls == 0) & (xcc == x)).sum())}, "
               f"sum of H lives {(t1 - t0)[(cls == 0) & (xcc == x)].sum() / 1e3:7.1f} ms")
     # who ends the launch?  the 24 workgroups that ended last, and per class how many ended in the last 5 / 10 / 20 us
-    names = {0: "H", 1: "M", 2: "V", 4: "lateM"}
+    names = {0: "H", 1: "M", 2: "V", 4: "lateM", 5: "Hset"}
     lastdisp = t0.max()
     print(f"  last dispatch at {lastdisp:.1f} us; launch ends {T - lastdisp:.1f} us later.  The 24 workgroups that ended last:")
     for k in np.argsort(t1)[::-1][:24]:
         print(f"    end {t1[k]:7.1f}  start {t0[k]:7.1f}  life {t1[k] - t0[k]:6.1f} us  class {names.get(int(cls[k]), '?'):5s} unit {int(r['unit'][k]):6d}  XCC {int(xcc[k])}")
     for w in (5.0, 10.0, 20.0):
         sel = t1 > T - w
-        print(f"  ended in the last {w:4.0f} us: " + ", ".join(f"{names[c]} {int((sel & (cls == c)).sum())}" for c in (4, 0, 1, 2)))
+        print(f"  ended in the last {w:4.0f} us: " + ", ".join(f"{names[c]} {int((sel & (cls == c)).sum())}" for c in (4, 0, 5, 1, 2)))

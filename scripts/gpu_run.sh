@@ -104,9 +104,9 @@ PY
         done; done
       rm -rf "$OUT"/pmc_*_?;;
   unitstrace) hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/units_trace profiles/microbench/units_trace.hip 2> "$OUT/build_units_trace.log"
-      for A in ${ARG:-cfg2,0,0 chunk_l1,0,0}; do   # workload,cycle test,m_late
+      for A in ${ARG:-cfg2,0,0,0 chunk_l1,0,0,0}; do   # workload,cycle test,m_late,h_settled
         set -- ${A//,/ }; W=$1; N=units_trace_${A//,/_}
-        timeout 300 /tmp/units_trace $W "$OUT/$N.bin" ${2:-0} ${3:-0} > "$OUT/$N.txt" 2>&1
+        timeout 300 /tmp/units_trace $W "$OUT/$N.bin" ${2:-0} ${3:-0} ${4:-0} > "$OUT/$N.txt" 2>&1
         timeout 600 python scripts/analyze_units_trace.py "$OUT/$N.bin" >> "$OUT/$N.txt" 2>&1
         grep -v "^  *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]*$" "$OUT/$N.txt" | tail -48; rm -f "$OUT/$N.bin"
       done;;
@@ -126,7 +126,8 @@ PY
       done;;
   ab) for rep in 1 2; do for W in ${ABW:-cfg2 chunk_l1 cfg3}; do
         b ${W}_base_$rep --workload $W --no-cpu-baseline --no-extras
-        b ${W}_${ARG//=/}_$rep --workload $W --no-cpu-baseline --no-extras --opt "$ARG"
+        OPTS=""; for o in ${ARG//+/ }; do OPTS="$OPTS --opt $o"; done     # ab:a=1+b=2 sets both
+        b ${W}_${ARG//[=+]/}_$rep --workload $W --no-cpu-baseline --no-extras $OPTS
       done; done;;
   abprev) # same-box A/B of the tree against a copy of an earlier commit built under .ab/prev (git archive REV bench.py distributedmandelbrot_amd include oracle)
       for rep in 1 2; do for W in ${ABW:-cfg2 chunk_l1}; do

@@ -33,6 +33,23 @@ print(f"  bound of a perfect pipeline: sum of max(kernel, d2h) per tile = {sum(m
 nslots = dev.SLOTS
 pins = [dev.pinned_empty((16777216,), np.uint8) for _ in range(nslots)]
 tiles = [(ir, ii) for ir in range(level) for ii in range(level)]
+# host time per tile of the two calls, by kind of tile (MBK_LAZY_UNIFORM, all slots in flight)
+acc = {}
+inflight_kind = {}
+for i in range(n + nslots):
+    if i >= nslots:
+        t0 = time.perf_counter()
+        st = dev.wait((i - nslots) % nslots)
+        dt = time.perf_counter() - t0
+        kind = "host-answered" if st.kernel_ms == 0.0 else "uniform, computed" if (st.all_bytes_zero or st.all_bytes_one) else "copied"
+        a = acc.setdefault(kind, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += inflight_kind.pop(i - nslots); a[2] += dt
+    if i < n:
+        t0 = time.perf_counter()
+        dev.submit_datachunk(i % nslots, level, mrd, *tiles[i], pins[i % nslots], lazy_uniform=True)
+        inflight_kind[i] = time.perf_counter() - t0
+for kind, (k, ts, tw) in sorted(acc.items()):
+    print(f"  host time per tile, {kind:18s}: {k:4d} tiles, submit {ts / k * 1e6:6.1f} us, wait {tw / k * 1e6:6.1f} us")
 for lazy in (False, True):
     for k in range(2, nslots + 1):
         best, uniform, its2 = None, 0, 0
@@ -51,3 +68,36 @@ for lazy in (False, True):
         assert its2 == its, (its2, its)
         print(f"{k} in flight{', MBK_LAZY_UNIFORM (' + str(uniform) + ' uniform tiles not copied)' if lazy else ''}: "
               f"{n} tiles in {best:.4f} s = {n/best:.1f} tiles/s")
+
+# two contexts on the one GPU, a host thread each (what `worker ADDR PORT 0,0` runs: two feeders): the host's per-tile work
+# -- a dozen HIP calls -- is what bounds the all-exterior stretches of a level, and it parallelises
+import threading
+dev2 = MandelbrotDevice(0)
+for item in sys.argv[3:]:
+    k, _, v = item.partition("=")
+    dev2.set_option(k, int(v))
+pins2 = [dev2.pinned_empty((16777216,), np.uint8) for _ in range(nslots)]
+
+
+def half(d, pp, mine, out):
+    k, its3 = nslots, 0
+    m = len(mine)
+    for i in range(m + k):
+        if i >= k:
+            its3 += d.wait((i - k) % k).pixel_iterations
+        if i < m:
+            d.submit_datachunk(i % k, level, mrd, *mine[i], pp[i % k], lazy_uniform=True)
+    out.append(its3)
+
+
+for rep in range(2):
+    out = []
+    th = [threading.Thread(target=half, args=(dev, pins, tiles[0::2], out)), threading.Thread(target=half, args=(dev2, pins2, tiles[1::2], out))]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    d = time.perf_counter() - t0
+    assert sum(out) == its
+print(f"two contexts x {nslots} in flight, two host threads, MBK_LAZY_UNIFORM: {n} tiles in {d:.4f} s = {n/d:.1f} tiles/s")

@@ -103,3 +103,58 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split() == ["-1", "0", "1", "1", "1", "16777216"]
+
+
+def test_literal_doubling_guard_matches_a_scan_of_every_row():
+    """validate_view's guard for the fma(2, zr*zi, ci) rewrite: a window needs the literal (2*zr)*zi kernels when
+    one of its rows has 0 < |ci| < 2^-900 (binary32: 2^-100 after the cast).  Round 5 replaced the scan of every row by two
+    binary searches over the monotonic axis; here against the scan (np.linspace IS the axis: tests/test_oracle.py), on axes
+    that cross zero with tiny residues, land on zero exactly, stay away from it, run backwards, and on windows that include
+    or exclude the crossing and the pinned last sample."""
+    import ctypes as C
+    import numpy as np
+    from distributedmandelbrot_amd import _lib as L
+    lib = L.load()
+    rs = np.random.RandomState(3)
+
+    def guard(start_i, range_i, h, row0, nrows, f32):
+        cv = L.mbk_view(-1.0, start_i, 2.0, range_i, 8, h, 0, row0, 8, nrows)
+        out = C.c_int(-1)
+        assert lib.mbk_view_needs_literal_doubling(C.byref(cv), L.MBK_PRECISION_F32 if f32 else 0, C.byref(out)) == L.MBK_OK
+        return bool(out.value)
+
+    def scan(start_i, range_i, h, row0, nrows, f32):
+        ys = np.linspace(start_i, start_i + range_i, h)[row0:row0 + nrows]
+        if f32:
+            ys = ys.astype(np.float32).astype(np.float64)
+        a = np.abs(ys)
+        return bool(((a != 0.0) & (a < (2.0 ** -100 if f32 else 2.0 ** -900))).any())
+
+    hits = 0
+    for trial in range(3000):
+        h = int(rs.choice([1, 2, 3, 7, 64, 513, 4096]))
+        kind = trial % 6
+        if kind == 0:      # tiny multiples of a tiny unit around zero
+            u = 2.0 ** float(rs.randint(-1060, -880))
+            start_i, range_i = -u * rs.randint(0, 9), u * rs.randint(1, 40)
+        elif kind == 1:    # ordinary axis crossing zero (residues ~1e-17: not tiny)
+            start_i, range_i = -rs.uniform(0.1, 2.0), rs.uniform(0.1, 4.0)
+        elif kind == 2:    # lands on zero exactly
+            n = max(h - 1, 1)
+            step = 2.0 ** float(rs.randint(-8, 2))
+            start_i, range_i = -step * rs.randint(0, n + 1), step * n
+        elif kind == 3:    # backwards, tiny
+            u = 2.0 ** float(rs.randint(-1000, -890))
+            start_i, range_i = u * rs.randint(0, 9), -u * rs.randint(1, 40)
+        elif kind == 4:    # binary32-tiny only
+            u = 2.0 ** float(rs.randint(-140, -90))
+            start_i, range_i = -u * rs.randint(0, 9), u * rs.randint(1, 40)
+        else:              # away from zero
+            start_i, range_i = rs.uniform(0.5, 1.0) * rs.choice([-1, 1]) * 2.0, rs.uniform(-0.4, 0.4)
+        row0 = int(rs.randint(0, h))
+        nrows = int(rs.randint(1, h - row0 + 1))
+        for f32 in (False, True):
+            want = scan(start_i, range_i, h, row0, nrows, f32)
+            assert guard(start_i, range_i, h, row0, nrows, f32) == want, (start_i, range_i, h, row0, nrows, f32)
+            hits += want
+    assert 300 < hits < 5000, hits

@@ -415,6 +415,8 @@ OPTION_MATRIX = [
     ("default", {"xcd_balance": 2, "cycle_detect": 0}),
     ("group", {"order": 3, "m_late": 0}), ("group", {"order": 3, "m_late": 4, "cycle_detect": 0, "xcd_balance": 2, "units_min_light": 0}),
     ("default", {"m_late": 31}), ("group", {"order": 3, "m_late": 12, "units_min_light": 0}), ("default", {"m_late": 65536, "xcd_balance": 1, "cycle_detect": 0}),
+    ("group", {"order": 3, "h_settled": 0}), ("group", {"order": 3, "h_settled": 1, "m_late": 0, "xcd_balance": 2, "units_min_light": 0}),
+    ("default", {"h_settled": 30}), ("group", {"order": 3, "h_settled": 9, "cycle_detect": 0}),
 ]
 
 

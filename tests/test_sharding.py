@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 import json
+import time
 
 import numpy as np
 import pytest
@@ -351,3 +352,59 @@ def test_real_bench_two_ranks_share_the_gpu_cfg3_bands():
     assert min(cfg["bands_per_rank"]) > 0 and len({r["pid"] for r in cfg["ranks_seen"]}) == 2
     assert cfg["pixel_iterations_per_step_per_gpu"] * 2 > 6.0e10   # the whole image's work was measured (~65 G)
     assert "error" not in rec["single_gpu_same_job"] and rec["single_gpu_same_job"]["value"] > 1000.0
+
+
+def test_bench_fails_fast_when_ranks_exceed_gpus():
+    """more ranks than visible GPUs without --oversubscribe is one line and a non-zero exit, not N ranks
+    dying one by one (here: no GPU at all, 3 ranks asked for)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MBK_BENCH_FAKE")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # also on a GPU box: hide them
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and time.monotonic() - t0 < 60
+    assert "--gpus 3 but only 0 GPU(s) visible" in out.stderr and "--oversubscribe" in out.stderr, out.stderr[-500:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_golden_outputs_describe_the_bench_workloads():
+    """tests/golden/bench_outputs.json (CPU oracle; tests/golden/make_bench_golden.py) is what bench.py's `output_verified`
+    fields compare against: every entry must describe exactly the view / mrd / precision / window bench.py times."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(bench.GOLDEN_OUTPUTS) as f:
+        g = json.load(f)
+    assert "cfg2" in g and set(bench.EXTRA_CONFIGS) <= set(g), sorted(g)
+    for name, e in g.items():
+        wl, window = (name, None) if name in bench.WORKLOADS else bench.EXTRA_CONFIGS[name][:2]
+        sr, si, rng, w, h, mrd, _ = bench.WORKLOADS[wl]
+        assert e["view"] == [sr, si, rng, rng, w, h] and e["mrd"] == mrd, name
+        assert e["precision"] == bench.DEFAULT_PRECISION.get(wl, "f64") and (tuple(e["window"]) if e["window"] else None) == window, name
+        assert len(e["counts_sha256"]) == 64 and e["pixel_iterations"] > 0
+    # the headline's totals are the ones DESIGN.md and the verdicts quote
+    assert g["cfg2"]["pixel_iterations"] == 2879480177 and g["cfg2"]["never_pixels"] == 2814248
+
+
+@pytest.mark.gpu
+def test_real_bench_default_line_pins_its_outputs_and_shows_every_config():
+    """The command the driver runs (`python bench.py --gpus 1 --steps K --warmup W`): the timed launches' own buffer hashes
+    to the CPU oracle's counts (strict leg and cycle-test leg), and the line carries a short strict leg of every other
+    single-GPU BASELINE config, each verified the same way."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MBK_BENCH_FAKE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["output_verified"]["verified"] is True, rec["output_verified"]
+    assert rec["cycle_detection"]["output_verified"]["verified"] is True
+    assert rec["config"]["xcd_balance"].startswith("1 for this leg only")
+    cfgs = rec["configs"]
+    assert set(cfgs) == {"cfg3", "cfg5", "chunk_l1", "cfg4_band"}, cfgs.get("error")
+    for name, c in cfgs.items():
+        assert "error" not in c, (name, c)
+        assert c["output_verified"]["verified"] is True, (name, c["output_verified"])
+        assert c["value"] > 1000.0 and 0.2 < c["roofline"]["frac"] < 0.66, (name, c["value"], c["roofline"]["frac"])
+    assert cfgs["cfg4_band"]["dtype"] == "f32" and cfgs["cfg3"]["pixel_iterations_per_step"] == 65146485486
+    e2e = rec["end_to_end"]
+    assert e2e["slots"] == 4 and e2e["tiles_per_s_all_slots_in_flight_lazy_uniform"] > e2e["tiles_per_s_synchronous"]
