@@ -384,6 +384,16 @@ def test_bench_golden_outputs_describe_the_bench_workloads():
         assert len(e["counts_sha256"]) == 64 and e["pixel_iterations"] > 0
     # the headline's totals are the ones DESIGN.md and the verdicts quote
     assert g["cfg2"]["pixel_iterations"] == 2879480177 and g["cfg2"]["never_pixels"] == 2814248
+    # ... and the committed hashes are the SCALAR oracle's (the generator used the AVX-512 evaluation where it exists):
+    # recomputed here for the two 4096^2 mrd-1000 tiles (~2 s)
+    import hashlib
+    from oracle.oracle import COracle
+    o = COracle()
+    for name in ("cfg2", "chunk_l1"):
+        sr, si, rng, w, h, mrd, _ = bench.WORKLOADS[name]
+        counts, _, total = o.view(sr, si, rng, rng, w, h, mrd, want_bytes=False)
+        assert hashlib.sha256(np.ascontiguousarray(counts, dtype="<i4").tobytes()).hexdigest() == g[name]["counts_sha256"], name
+        assert total == g[name]["pixel_iterations"] and int((counts == 0).sum()) == g[name]["never_pixels"]
 
 
 @pytest.mark.gpu
