@@ -142,8 +142,12 @@ def parse_args(argv=None):
                          "that the ranks pull from a shared-memory cursor (strong scaling; the per-GPU work queue of the "
                          "north star). bands: ONE view per step, cut into >= 16 row bands per GPU pulled from the cursor "
                          "(strong scaling; how BASELINE cfg3 shards an image over 8 GPUs)")
-    ap.add_argument("--queue-order-image", action="store_true",
-                    help="--shard queue: hand the tiles of a step out in image order instead of longest first")
+    ap.add_argument("--queue-order", default="image", choices=["image", "longest"],
+                    help="--shard queue: the order in which the tiles of a step are handed out.  image (default since round 5): the "
+                         "order a Distributer walks its own list in (Distributer.cs:335-353) -- what a deployment gets.  longest: by "
+                         "the census' pixel-iterations, longest first (rounds 3-4's default: the ranks finish together, which a real "
+                         "server does not arrange; ADVICE r4)")
+    ap.add_argument("--queue-order-image", action="store_true", help=argparse.SUPPRESS)   # (round 4's flag: now the default)
     ap.add_argument("--grid", type=int, default=8, help="--shard queue: the job is grid x grid tiles (default 8 -> 64 tiles per step)")
     ap.add_argument("--band-rows", type=int, default=0, help="rows per band for --shard bands (default: height / (16 N), >= 128)")
     ap.add_argument("--streams", type=int, default=None,
@@ -713,10 +717,10 @@ def main():
     per_tile = None
     if queue_mode:
         per_tile = census()
-        # hand the tiles of a step out longest first (by the census' pixel-iterations; every rank holds the same table):
+        # --queue-order longest: hand the tiles of a step out longest first (by the census' pixel-iterations; every rank holds the same table):
         # the last tickets of the run are then the cheapest tiles, so the ranks finish together -- the order a
         # Distributer hands tiles out in is the server's choice (Distributer.cs:335-353 walks its own list)
-        if not args.queue_order_image:
+        if args.queue_order == "longest":
             units = sorted(units, key=lambda u: (-per_tile[u][0], u))
         barrier()
         if rank == 0:
@@ -928,7 +932,8 @@ def main():
             tile_iters = [per_tile[k][0] for k in range(ntiles)]
             cfg.update({"tiles_per_step": ntiles, "grid": args.grid, "tiles_exactly_once": once,
                         "tiles_per_rank": per_rank_units,
-                        "tile_order": "image order" if args.queue_order_image else "longest first within a step (census)",
+                        "tile_order": "longest first within a step (census)" if args.queue_order == "longest" else
+                                      "image order (the server's walk of its own list)",
                         "tile_pixel_iterations_min_max": [min(tile_iters), max(tile_iters)]})
         rec = {
             "metric": metric,
@@ -1058,7 +1063,8 @@ def queue_job_single(args, headline_value):
     per step, whose rate differs by the tiles' pitch)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--shard", "queue", "--no-cpu-baseline", "--no-extras",
-           "--workload", args.workload, "--kernel", args.kernel, "--grid", str(args.grid), "--steps", "3", "--warmup", "1"]
+           "--workload", args.workload, "--kernel", args.kernel, "--grid", str(args.grid), "--steps", "3", "--warmup", "1",
+           "--queue-order", args.queue_order]
     for item in args.opt:
         cmd += ["--opt", item]
     try:

@@ -43,6 +43,7 @@ struct StreamScratch {
     size_t order_cap = 0;         // regions
     unsigned order_turn = 0;
     hipStream_t aux = nullptr;    // the pre-pass stream
+    uint32_t aux_prio = 0;        // 1 default priority, 2 highest (MBK_OPT_PREPASS_OVERLAP = 2)
     hipEvent_t ev_cls[2] = {nullptr, nullptr};   // pre-pass into list k finished
     hipEvent_t ev_done[2] = {nullptr, nullptr};  // the tile kernel that read list k finished
     bool done_valid[2] = {false, false};
@@ -403,8 +404,30 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         int rc = get_scratch(ctx, stream, &sc);
         if (rc != MBK_OK) return rc;
         const bool overlap = ctx->opt[MBK_OPT_PREPASS_OVERLAP] != 0u;
+        // MBK_OPT_PREPASS_OVERLAP = 2: the auxiliary stream has the highest priority, so that the pre-pass of launch L + 1 gets
+        // its workgroups in while the tile kernel of launch L is in full swing instead of waiting for its drain (round 5: once
+        // the launch no longer ends in a 20 us drain, a pre-pass that waited for it sits on the critical path)
+        const uint32_t want_prio = ctx->opt[MBK_OPT_PREPASS_OVERLAP] == 2u ? 2u : 1u;
+        if (sc->aux && sc->aux_prio != want_prio) {
+            MBK_HIP(ctx, hipStreamSynchronize(stream));
+            MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
+            (void)hipStreamDestroy(sc->aux);
+            sc->aux = nullptr;
+            for (int k = 0; k < 2; ++k) {
+                if (sc->ev_cls[k]) (void)hipEventDestroy(sc->ev_cls[k]);
+                if (sc->ev_done[k]) (void)hipEventDestroy(sc->ev_done[k]);
+                sc->ev_cls[k] = sc->ev_done[k] = nullptr;
+                sc->done_valid[k] = false;
+            }
+        }
         if (!sc->aux) {
+            if (want_prio == 2u) {
+                int least = 0, greatest = 0;
+                MBK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                MBK_HIP(ctx, hipStreamCreateWithPriority(&sc->aux, hipStreamNonBlocking, greatest));
+            } else
             MBK_HIP(ctx, hipStreamCreateWithFlags(&sc->aux, hipStreamNonBlocking));
+            sc->aux_prio = want_prio;
             for (int k = 0; k < 2; ++k) {
                 MBK_HIP(ctx, hipEventCreateWithFlags(&sc->ev_cls[k], hipEventDisableTiming));
                 MBK_HIP(ctx, hipEventCreateWithFlags(&sc->ev_done[k], hipEventDisableTiming));
@@ -444,7 +467,8 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             const uint32_t hs = cyc ? ctx->opt[MBK_OPT_H_SETTLED] : 0u;
             const double settle_thr = hs ? std::pow(10.0, -(double)hs) : 0.0;
             MBK_HIP(ctx, hipMemsetAsync(ord + 2u * (size_t)grid.x + 3u, 0, 2 * sizeof(uint32_t), pre));   // counts: late M, settled H
-            hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a, grid.x,
+            const uint32_t cwg = ctx->opt[MBK_OPT_CLASSIFY_WG];
+            hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + cwg - 1u) / cwg), dim3(cwg), 0, pre, a, grid.x,
                                (int32_t)probe_steps, ord, cursors, (int32_t)ctx->opt[MBK_OPT_M_LATE], settle_thr);
             // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
             // stream, 2 a fixed uneven deal (tests)
@@ -1043,7 +1067,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u};
+        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1564,7 +1588,8 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_RF_WAVES: ok = value >= 1u && value <= 8u; break;
         case MBK_OPT_CYCLE_DETECT: ok = value <= 1u; break;
         case MBK_OPT_PROBE_MID: ok = value >= 2u && value <= 65537u; break;
-        case MBK_OPT_PREPASS_OVERLAP: ok = value <= 1u; break;
+        case MBK_OPT_PREPASS_OVERLAP: ok = value <= 2u; break;
+        case MBK_OPT_CLASSIFY_WG: ok = value >= 64u && value <= 1024u && value % 64u == 0u; break;
         case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;

@@ -280,7 +280,8 @@ enum mbk_option {
                               and must stay interleaved with the boundary blocks, so the default is off */
     MBK_OPT_PREPASS_OVERLAP, /* asm/group: run the dispatch-order pre-pass (memset + classify, 13 us on cfg2) on an auxiliary
                               stream, into one of two alternating lists, so that it overlaps the PREVIOUS launch's tile
-                              kernel on the caller's stream (the tile kernel waits for its list through an event): 0, [1] */
+                              kernel on the caller's stream (the tile kernel waits for its list through an event): 0, [1], 2 = the
+                              same with the auxiliary stream at the highest priority the device offers */
     MBK_OPT_EXACT_LONG,    /* group / scan pass 2: cap on exact_steps for the blocks that run 16-step groups (classified as
                               interior, where hardly any lane escapes early -- and one that does costs a trip plus the
                               block's single fix-up): [0] = no per-step prologue for them .. 4096 (cfg2 +0.4 %, inset +0.5 %) */
@@ -316,6 +317,10 @@ enum mbk_option {
                               steps; the settled ones are dispatched behind the others, so that the last interior blocks to
                               start are short ones: 0 (one list), k = 1..30 [6].  Measured only together with M late
                               (profiles/r05).  Changes when a block is computed, never what is stored */
+    MBK_OPT_CLASSIFY_WG,   /* order 3: threads per workgroup of the probe pre-pass, a multiple of 64: 64 .. [1024].  The pre-pass of launch
+                              L + 1 runs beside the tile kernel of launch L (MBK_OPT_PREPASS_OVERLAP); a 1024-thread workgroup needs
+                              16 free wave slots on ONE CU at once, which a chip full of single-wave workgroups offers only in its
+                              drain */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

@@ -110,6 +110,30 @@ PY
         timeout 600 python scripts/analyze_units_trace.py "$OUT/$N.bin" >> "$OUT/$N.txt" 2>&1
         grep -v "^  *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]*$" "$OUT/$N.txt" | tail -48; rm -f "$OUT/$N.bin"
       done;;
+  extprobe) # the host-buffer pipeline on all-exterior tiles: rate by slots, then the HIP calls and the GPU side of it
+      for K in 1 2 4; do timeout 120 python scripts/exterior_pipeline_probe.py 2000 $K 1 2>&1 | grep -v amdgpu.ids; done | tee "$OUT/exterior_pipeline.txt"
+      timeout 120 python scripts/exterior_pipeline_probe.py 2000 4 0 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/exterior_pipeline.txt"
+      (cd /tmp && timeout 600 rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --stats --output-format csv -d "$OUT/extprobe" -o t -- python "$ROOT/scripts/exterior_pipeline_probe.py" 2000 4 1 > "$OUT/extprobe.log" 2>&1)
+      tail -1 "$OUT/extprobe.log" | tee -a "$OUT/exterior_pipeline.txt"
+      for f in hip_api_stats kernel_stats memory_copy_stats; do g=$(find "$OUT/extprobe" -name "*${f}.csv" | head -1); [ -n "$g" ] && { echo "-- $f"; cut -d, -f1-6 "$g" | head -14; cp "$g" "$OUT/extprobe_${f}.csv"; }; done | tee -a "$OUT/exterior_pipeline.txt"
+      python - "$OUT/extprobe" <<'PY' | tee -a "$OUT/exterior_pipeline.txt"
+import csv, glob, os, sys
+import numpy as np
+p = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)
+if p:
+    rows = list(csv.DictReader(open(p[0])))
+    nm = lambda r: r.get("Kernel_Name") or r.get("Name")
+    light = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "tile_light_kernel" in nm(r))
+    if len(light) > 100:
+        s = np.array([a for a, b in light][len(light) // 4:], float); e = np.array([b for a, b in light][len(light) // 4:], float)
+        print(f"light kernels: {len(light)}; duration mean {np.mean(e - s) / 1e3:.1f} us; start-to-start mean {np.mean(np.diff(s)) / 1e3:.1f} us (median {np.median(np.diff(s)) / 1e3:.1f}); overlapping the previous one: {np.mean(s[1:] < e[:-1]):.2f}")
+PY
+      rm -rf "$OUT/extprobe";;
+  gaps) # kernel-trace of back-to-back steps: tile kernel, gap, where the next launch's pre-pass ran.  gaps:W:OPT+OPT...
+      W=${ARG%%:*}; O=${ARG#*:}; [ "$O" = "$ARG" ] && O=""; OPTS=""; for o in ${O//+/ }; do OPTS="$OPTS --opt $o"; done
+      N=gaps_${W}_${O//[=+]/}
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/$N" -o t -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --workload $W --steps 150 --warmup 20 $OPTS > "$OUT/$N.log" 2>&1)
+      line "$OUT/$N.log"; python scripts/analyze_gaps.py "$OUT/$N" | tee "$OUT/$N.txt"; rm -rf "$OUT/$N";;
   skew) [ -x build/units_skew ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip 2> "$OUT/build_units_skew.log"
       for A in ${ARG:-cfg2,40,0.5 chunk_l1,40,0.5 cfg2,40,0.5,0,1,0 cfg2,40,0.5,0,1,1}; do   # workload,launches,gain[,rotation[,cycle test[,signal]]]
         timeout 120 build/units_skew ${A//,/ } > "$OUT/units_skew_${A//,/_}.txt" 2>&1; tail -4 "$OUT/units_skew_${A//,/_}.txt"

@@ -96,7 +96,7 @@ def simulate(world, nstreams, nsteps, nunits, unit_ms, guided):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04", "scale_prediction.json"))
-    ap.add_argument("--jobs", default="queue,cfg3_grid2,cfg3_grid4,cfg3_bands")
+    ap.add_argument("--jobs", default="queue,queue_longest,cfg3_grid2,cfg3_grid4,cfg3_bands")
     ap.add_argument("--worlds", default="1,2,4,8")
     ap.add_argument("--max-steps", type=int, default=0, help="cap the emulated steps per job (0 = bench.py's defaults)")
     ap.add_argument("--kernel", default="default")
@@ -118,10 +118,11 @@ def main():
         torch.cuda.synchronize()
 
     for job in args.jobs.split(","):
-        if job == "queue":
+        base_job = job[:-len("_longest")] if job.endswith("_longest") else job     # NAME_longest: --queue-order longest
+        if base_job == "queue":
             wl, mode, grid = "cfg2", "queue", 8
-        elif job.startswith("cfg3_grid"):
-            wl, mode, grid = "cfg3", "queue", int(job[len("cfg3_grid"):])
+        elif base_job.startswith("cfg3_grid"):
+            wl, mode, grid = "cfg3", "queue", int(base_job[len("cfg3_grid"):])
         elif job == "cfg3_bands":
             wl, mode, grid = "cfg3", "bands", 0
         elif job == "cfg2_bands":
@@ -175,12 +176,13 @@ def main():
             for u in range(ntiles):
                 unit_ms[u] = timed_alone(lambda: launch_tile(0, u))
                 iters[u] = dev.reduce_counts(bufs[0].data_ptr(), npix, mrd, stream=streams[0].cuda_stream).pixel_iterations
-            order = sorted(range(ntiles), key=lambda u: (-iters[u], u))      # bench.py: longest first within a step
+            # bench.py --queue-order: image (default since round 5: the server's walk) | longest (job name ending in _longest)
+            order = sorted(range(ntiles), key=lambda u: (-iters[u], u)) if job.endswith("_longest") else list(range(ntiles))
             unit_ms_in_order = [unit_ms[u] for u in order]
             iters_per_step = sum(iters.values())
             nunits = ntiles
             base_steps = max(2, d_steps * 4 // ntiles)
-            scheme = f"{ntiles} tiles of {width}x{height} per step ({grid}x{grid} grid over the {wl} region), longest first, {nstreams} in flight"
+            scheme = f"{ntiles} tiles of {width}x{height} per step ({grid}x{grid} grid over the {wl} region), {'longest first' if job.endswith('_longest') else 'image order'}, {nstreams} in flight"
         else:
             ramp(lambda: launch_rows(0, 0, height))
             launch_rows(0, 0, height)

@@ -196,7 +196,7 @@ def test_bench_self_launch_queue_default_world2():
     assert solo["steps"] == 3 and 0 < solo["value"] < rec["value"] * 1.05
     assert abs(rec["speedup_same_job"] - rec["value"] / solo["value"]) < 1e-9
     assert abs(rec["efficiency_same_job"] - rec["speedup_same_job"] / 2) < 1e-9 and rec["efficiency_same_job"] > 0.6
-    assert cfg["tile_order"].startswith("longest first")
+    assert cfg["tile_order"].startswith("image order")
 
 
 def test_bench_queue_default_steps_grow_with_the_ranks():
