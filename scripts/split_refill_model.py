@@ -148,3 +148,19 @@ for livemin in (32, 40, 48, 56, 60):
         cells.append(f"x{single / tot:.3f}")
     tot_busy = g_all + (st + ev * 12) * (6.25 / 6.125) / (0.90 / 0.96)
     print(f"   {livemin:5d}   {st / 1e6:8.1f} M  {ev / 1e6:6.2f} M   {ideal_rest / st:8.3f} |  " + "     ".join(cells) + f"          x{single / tot_busy:.3f}")
+
+# ---- the library's default (cycle test): the all-alive side keeps the cycle test (kernel `group`), the refill side has none --
+# its never-escaping pixels (few: they sit in blocks with an escaping pixel) run all mrd - 1 steps, each in a lane of its own
+t0 = time.time()
+ex = o.view_cycle(*view, N, N, mrd, first=8, check=8)[1]
+E = np.where(c == 0, ex, c).astype(np.int64).reshape(nb, 8, nb, 8).transpose(0, 2, 1, 3).reshape(-1, 64)   # executed steps per lane
+last_c = E.max(1)
+single_c = last_c.sum()
+print(f"cycle test (oracle.view_cycle, {time.time() - t0:.0f} s): one wave per block {single_c / 1e6:.1f} M wave-steps (lane activity {E.sum() / 64.0 / single_c:.4f}); "
+      f"the all-alive blocks hold {last_c[alive_all].sum() / single_c:.3f} of them at activity {E[alive_all].sum() / 64.0 / last_c[alive_all].sum():.3f}")
+for livemin in (40, 48):
+    st, ev = simulate(livemin, 0)          # the refill side runs the strict steps of its pixels
+    for cst in (12, 24):
+        tot = last_c[alive_all].sum() + (st + ev * cst) * (6.25 / 6.125)
+        print(f"   hybrid, refill without cycle test, livemin {livemin}, event cost {cst}: {tot / 1e6:.1f} M = x{single_c / tot:.3f} of the product's cycle-test launch "
+              f"(refill side {(st + ev * cst) / 1e6:.1f} M against {last_c[rest].sum() / 1e6:.1f} M now)")
