@@ -48,6 +48,7 @@ struct StreamScratch {
     // in turn, so that the pre-pass of a later launch (memset + classify, on the aux stream) can run while the tile
     // kernels of the launches before it still read the others
     uint32_t *d_order[kOrderRing] = {};
+    uint32_t *d_ctl = nullptr;    // 8 words per list: the units pre-pass' counters (H, V, M | late M, settled H, ticket), zero between launches
     size_t order_cap = 0;         // regions
     unsigned order_turn = 0;
     hipStream_t aux = nullptr;    // the pre-pass stream
@@ -274,6 +275,7 @@ static void free_scratch(StreamScratch &sc)
         if (sc.ev_done[k]) (void)hipEventDestroy(sc.ev_done[k]);
     }
     if (sc.aux) (void)hipStreamDestroy(sc.aux);
+    if (sc.d_ctl) (void)hipFree(sc.d_ctl);
     if (sc.d_queues) (void)hipFree(sc.d_queues);
     if (sc.d_queues_split) (void)hipFree(sc.d_queues_split);
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
@@ -639,16 +641,18 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         hipStream_t pre = overlap ? sc->aux : stream;
         if (overlap && sc->done_valid[k]) MBK_HIP(ctx, hipStreamWaitEvent(sc->aux, sc->ev_done[k], 0));
         // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
-        MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
         if (units) {
             // MBK_OPT_M_LATE = s > 0: M blocks whose centre pixel escapes at step >= s open the dispatch order; MBK_OPT_H_SETTLED
             // = k > 0 (with the cycle test only): H blocks whose probe orbit is within 10^-k of settled close the front list
             const uint32_t hs = cyc ? ctx->opt[MBK_OPT_H_SETTLED] : 0u;
             const double settle_thr = hs ? std::pow(10.0, -(double)hs) : 0.0;
-            MBK_HIP(ctx, hipMemsetAsync(ord + 2u * (size_t)grid.x + 3u, 0, 2 * sizeof(uint32_t), pre));   // counts: late M, settled H
-            const uint32_t cwg = ctx->opt[MBK_OPT_CLASSIFY_WG];
-            hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + cwg - 1u) / cwg), dim3(cwg), 0, pre, a, grid.x,
-                               (int32_t)probe_steps, ord, cursors, (int32_t)ctx->opt[MBK_OPT_M_LATE], settle_thr);
+            // the pre-pass' six counters live apart from the lists (whose layout moves with the window's size), are zeroed once
+            // here and put back to zero by the pre-pass itself (mbk_units.h: classify_units_kernel)
+            if (!sc->d_ctl) {
+                MBK_HIP(ctx, hipMalloc((void **)&sc->d_ctl, (size_t)kOrderRing * 8u * sizeof(uint32_t)));
+                MBK_HIP(ctx, hipMemset(sc->d_ctl, 0, (size_t)kOrderRing * 8u * sizeof(uint32_t)));
+            }
+            uint32_t *ctl = sc->d_ctl + 8u * k;
             // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
             // stream, 2 a fixed uneven deal (tests)
             // (1 applies to the strict loops only: with the cycle test a launch ends with the drain of its boundary blocks, which
@@ -678,11 +682,15 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             a.plan = ord + ((2u * (size_t)grid.x + 5u + 15u) & ~(size_t)15u);   // (ends below units_settled_base: + 16 + 40 <= + 64)
             a.stamps = balance == 1u ? sc->h_stamps + (size_t)(seq % kStampSlots) * mbk::kStampWords : nullptr;
             a.stamp_tag = seq & 0xffffu;
-            hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)cursors,
-                               (const uint32_t *)(ord + 2u * (size_t)grid.x + 3u), w, a.stamps ? 1u : 0u, (uint32_t *)a.plan);
-        } else
+            const uint32_t cwg = ctx->opt[MBK_OPT_CLASSIFY_WG];
+            hipLaunchKernelGGL(mbk::classify_units_kernel, dim3((grid.x + cwg - 1u) / cwg), dim3(cwg), 0, pre, a, grid.x,
+                               (int32_t)probe_steps, ord, ctl, (int32_t)ctx->opt[MBK_OPT_M_LATE], settle_thr, ctl + 3, (uint32_t *)a.plan, w,
+                               a.stamps ? 1u : 0u);
+        } else {
+        MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a,
                            grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
+        }
         if (overlap) {
             MBK_HIP(ctx, hipEventRecord(sc->ev_cls[k], sc->aux));
             MBK_HIP(ctx, hipStreamWaitEvent(stream, sc->ev_cls[k], 0));
@@ -805,6 +813,7 @@ static int launch_refill(mbk_ctx *ctx, const TileArgs &a, bool safe, hipStream_t
     if (icols == 0 || irows == 0) return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, false, stream);
 
     mbk::PersistArgs q;
+    std::memset(&q, 0, sizeof(q));      // (list = nullptr: the blocks of the window in image order)
     q.re_start = a.re.start;
     q.re_step = a.re.step;
     q.im_start = a.im.start;
@@ -1824,7 +1833,7 @@ int mbk_units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const double *fract
     if ((uint64_t)n_h + n_v + n_m > 0x7fffffffull) return MBK_ERR_INVALID;
     uint32_t cum[8];
     shares_from_fractions(fractions, cum);
-    mbk::units_plan(n_h, n_v, n_m, cum, 0u, plan);
+    mbk::units_plan(n_h, n_v, n_m, cum, 0u, plan, 0u, 0u);
     return MBK_OK;
 }
 

@@ -56,6 +56,10 @@ __host__ __device__ inline size_t units_list_words(size_t n) { return 3u * n + 6
 // centre escapes at step >= m_late are filed apart and dispatched FIRST, before H; the rest of M and the V units stay behind
 // H as the filler of its drain.
 //
+struct XcdShares { uint32_t cum[8]; };   // front list: share of XCDs 0..x, in 2^-24 (cum[7] = 2^24)
+__host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const uint32_t *cum, uint32_t stamps, uint32_t *plan,
+                                           uint32_t n_ml, uint32_t n_hs);
+
 // H SETTLED (round 5, with the cycle test only).  With the cycle test the H class is no longer uniform: a block whose orbits
 // have settled on their attracting cycle retires within a few checks (cfg2: 27 669 of 47 683 H blocks, 194 steps on
 // average), one whose orbits have not runs (nearly) all mrd - 1 steps (20 014 blocks, 772 on average, 98.5 % of those that run
@@ -66,32 +70,48 @@ __host__ __device__ inline size_t units_list_words(size_t n) { return 3u * n + 6
 // dispatched behind the unsettled ones.  (On its own -- without M late -- this order LOST 1.8 % on cfg2: profiles/r05/README.)
 __device__ __forceinline__ int32_t probe_settling(double cr, double ci, int32_t cap, double *delta)
 {
-    double zr = cr, zi = ci, sr[7], si[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) sr[k] = si[k] = 1e300;
-    for (int32_t n = 1; n < cap; ++n) {
+    double zr = cr, zi = ci;
+    int32_t n = 1;
+    for (; n < cap - 9; ++n) {                 // the plain loop; the history matters for the last nine states only
         const double t = zr * zr - zi * zi;
         zi = __builtin_fma(2.0, zr * zi, ci);
         zr = t + cr;
         if (zr * zr + zi * zi >= 4.0) { *delta = 1e300; return n; }
-        const int32_t back = cap - 1 - n;        // this state is z_(last - back)
+    }
+    double hr[9], hi[9];                       // hr[p] = z_(last - p) once the loop is through
 #pragma unroll
-        for (int k = 0; k < 7; ++k)
-            if (back == (k < 6 ? k + 1 : 8)) { sr[k] = zr; si[k] = zi; }
+    for (int k = 0; k < 9; ++k) hr[k] = hi[k] = 1e150;
+    for (; n < cap; ++n) {
+        const double t = zr * zr - zi * zi;
+        zi = __builtin_fma(2.0, zr * zi, ci);
+        zr = t + cr;
+        if (zr * zr + zi * zi >= 4.0) { *delta = 1e300; return n; }
+#pragma unroll
+        for (int k = 8; k > 0; --k) { hr[k] = hr[k - 1]; hi[k] = hi[k - 1]; }
+        hr[0] = zr;
+        hi[0] = zi;
     }
     double d = 1e300;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const double dr = zr - sr[k], di = zi - si[k], q = dr * dr + di * di;
+    for (int k = 1; k <= 8; ++k) {
+        if (k == 7) continue;
+        const double dr = hr[0] - hr[k], di = hi[0] - hi[k], q = dr * dr + di * di;
         d = q < d ? q : d;
     }
     *delta = d;
     return 0;
 }
 
+// counters[0..3): H, V units, M; extra[0..3): late M, settled H, a ticket.  With `plan` the workgroup that finishes last turns
+// the counts into the XCD shares itself (units_plan: what units_plan_kernel does in a launch of its own) and clears the six
+// words for the next launch that uses them -- the pre-pass is then ONE kernel instead of fill + classify + plan, three
+// dependent launches of a few microseconds each that sit between two tile kernels once a launch no longer ends in a long drain
+// (profiles/r05/gaps_*.txt).  The caller zeroes the six words once, when it allocates them.
 __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
-                                                              uint32_t *order, uint32_t *counters, int32_t m_late, double settle_thr)
+                                                              uint32_t *order, uint32_t *counters, int32_t m_late, double settle_thr,
+                                                              uint32_t *extra, uint32_t *plan, XcdShares shares, uint32_t stamps)
 {
+    __shared__ uint32_t s_last;
     __shared__ uint32_t s_cnt[5][16], s_base[5];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -131,7 +151,7 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
             s_cnt[k][w] = t;
             t += c;
         }
-        s_base[k] = t ? atomicAdd(k < 3u ? &counters[k] : &order[2u * nregions + k], t) : 0u;   // [2n+3] late M, [2n+4] settled H
+        s_base[k] = t ? atomicAdd(k < 3u ? &counters[k] : &extra[k - 3u], t) : 0u;
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -140,6 +160,21 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
     if (emit[2]) order[nregions + 3u + s_base[2] + s_cnt[2][wave] + (uint32_t)__popcll(m[2] & below)] = (by << 16) | bx;
     if (emit[3]) order[2u * nregions + 2u - (s_base[3] + s_cnt[3][wave] + (uint32_t)__popcll(m[3] & below))] = (by << 16) | bx;
     if (emit[4]) order[units_settled_base(nregions) + s_base[4] + s_cnt[4][wave] + (uint32_t)__popcll(m[4] & below)] = (by << 16) | bx;
+    if (plan == nullptr) return;
+    // the last workgroup to get here: every other one has added its counts (its atomics precede its ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(&extra[2], 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last != 0u && threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t n_h = atomicExch(&counters[0], 0u), n_v = atomicExch(&counters[1], 0u), n_m = atomicExch(&counters[2], 0u);
+        const uint32_t n_ml = atomicExch(&extra[0], 0u), n_hs = atomicExch(&extra[1], 0u);
+        atomicExch(&extra[2], 0u);
+        units_plan(n_h + n_ml + n_hs, n_v, n_m, shares.cum, stamps, plan, n_ml, n_hs);
+    }
 }
 
 // ---- Shares of the eight XCDs ------------------------------------------------------------------------------------------
@@ -159,12 +194,11 @@ constexpr uint32_t kPlanWords = 40;  // [0] H entries [1] M entries [2] ids in a
                                      // [5] 1 = this launch leaves time stamps [6] late M entries: the first [6] of the [0] front
                                      // entries [7] where the settled H entries begin in the front list
                                      // [8..16) h[x]  [16..24) l[x]  [24..32) H base[x]  [32..40) light base[x]
-struct XcdShares { uint32_t cum[8]; };   // H list: share of XCDs 0..x, in 2^-24 (cum[7] = 2^24)
 
 // (host and device: mbk_units_plan / mbk_units_lookup of the C ABI run the same lines for the CPU tests)
 // (n_h: the entries of the FRONT list = the n_ml late M entries, the unsettled H entries, the n_hs settled ones; n_m: the other M)
 __host__ __device__ inline void units_plan(uint32_t n_h, uint32_t n_v, uint32_t n_m, const uint32_t *cum, uint32_t stamps, uint32_t *plan,
-                                           uint32_t n_ml = 0u, uint32_t n_hs = 0u)
+                                           uint32_t n_ml, uint32_t n_hs)
 {
     const uint32_t n_l = n_m + n_v, total = n_h + n_l;
     uint32_t h[8], l[8], prev = 0, slots = (total + 7u) >> 3;
@@ -213,7 +247,7 @@ __global__ void units_plan_kernel(const uint32_t *counters, const uint32_t *late
 {
     // (late = order + 2n + 3: the counts of late M entries, which open the front list, and of settled H entries, which end it)
     if (threadIdx.x == 0 && blockIdx.x == 0)
-        units_plan(counters[0] + late[0] + late[1], counters[1], counters[2], w.cum, stamps, plan, late[0], late[1]);
+        units_plan(counters[0] + late[0] + late[1], counters[1], counters[2], w.cum, stamps, plan, late[0], late[1]);   // (split path, microbenchmarks)
 }
 
 // The eleven words of the plan a workgroup of XCD x needs, with scalar loads issued together (scalar_load_u32's comment)

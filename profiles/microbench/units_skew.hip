@@ -155,7 +155,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     uint32_t cnt[3] = {0, 0, 0};
     CHECK(hipMemset(ord + nblocks, 0, 12));
-    mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, 0, 0.0);
+    mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, 0, 0.0, ord + 2 * (size_t)nblocks + 3, nullptr, mbk::XcdShares(), 0u);
     CHECK(hipMemcpy(cnt, ord + nblocks, 12, hipMemcpyDeviceToHost));
     const uint32_t n_h = cnt[0], n_v = cnt[1], n_m = cnt[2];
     printf("%s: H %u, V units %u, M %u; controller gain %.2f, rotation %u, cycle test %d, signal %s\n", wl.c_str(), n_h, n_v, n_m, gain, rot, (int)cyc,

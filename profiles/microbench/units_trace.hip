@@ -96,7 +96,7 @@ int main(int argc, char **argv)
     for (int rep = 0; rep < 160; ++rep) {      // (the clock needs ~100 launches to settle; the last launch is the one recorded)
         CHECK(hipMemset(ord + nblocks, 0, 12));
         CHECK(hipMemset(ord + 2 * (size_t)nblocks + 3, 0, 8));
-        mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, m_late, settle_thr);
+        mbk::classify_units_kernel<<<(nblocks + 1023) / 1024, 1024>>>(a, nblocks, 32, ord, ord + nblocks, m_late, settle_thr, ord + 2 * (size_t)nblocks + 3, nullptr, mbk::XcdShares(), 0u);
         CHECK(hipMemcpy(cnt, ord + nblocks, 12, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(&n_ml, ord + 2 * (size_t)nblocks + 3, 4, hipMemcpyDeviceToHost));
         CHECK(hipMemcpy(&n_hs, ord + 2 * (size_t)nblocks + 4, 4, hipMemcpyDeviceToHost));

@@ -129,6 +129,14 @@ if p:
         print(f"light kernels: {len(light)}; duration mean {np.mean(e - s) / 1e3:.1f} us; start-to-start mean {np.mean(np.diff(s)) / 1e3:.1f} us (median {np.median(np.diff(s)) / 1e3:.1f}); overlapping the previous one: {np.mean(s[1:] < e[:-1]):.2f}")
 PY
       rm -rf "$OUT/extprobe";;
+  traceopt) # kernel-trace stats of one workload under options: traceopt:W:OPT+OPT[:extra bench args with commas for spaces]
+      W=${ARG%%:*}; R=${ARG#*:}; O=${R%%:*}; X=${R#*:}; [ "$X" = "$R" ] && X=""; OPTS=""; for o in ${O//+/ }; do OPTS="$OPTS --opt $o"; done
+      trace ${W}_${O//[=+]/} --workload $W --no-extras $OPTS ${X//,/ }; f="$OUT/${W}_${O//[=+]/}_kernel_stats.csv"; [ -f "$f" ] && python - "$f" <<'PY'
+import csv, sys
+for r in csv.reader(open(sys.argv[1])):
+    if r[0] != "Name": print(f"     {r[0][:70]:70s} calls {r[1]:>6s} avg {float(r[3]) / 1e3:10.1f} us  total {float(r[2]) / 1e6:9.1f} ms")
+PY
+      ;;
   gaps) # kernel-trace of back-to-back steps: tile kernel, gap, where the next launch's pre-pass ran.  gaps:W:OPT+OPT...
       W=${ARG%%:*}; O=${ARG#*:}; [ "$O" = "$ARG" ] && O=""; OPTS=""; for o in ${O//+/ }; do OPTS="$OPTS --opt $o"; done
       N=gaps_${W}_${O//[=+]/}
