@@ -22,7 +22,6 @@
 #include "mbk_persist.h"
 #include "mbk_scan.h"
 #include "mbk_units.h"
-#include "mbk_split.h"
 #include "mbk_feeder.h"
 
 using mbk::Axis;
@@ -56,8 +55,7 @@ struct StreamScratch {
     hipEvent_t ev_cls[kOrderRing] = {};   // pre-pass into list k finished
     hipEvent_t ev_done[kOrderRing] = {};  // the tile kernel that read list k finished
     bool done_valid[kOrderRing] = {};
-    WorkQueues *d_queues = nullptr;  // kernel "refill"; the split of deep zooms uses two, alternately (index = its list's)
-    WorkQueues *d_queues_split = nullptr;   // two sets
+    WorkQueues *d_queues = nullptr;  // kernel "refill"
     mbk::ScanCursors *d_cursors = nullptr;  // kernel "scan": two sets, used alternately
     uint32_t *d_entries = nullptr;   // kernel "scan": the 64 todo lists (block ids)
     size_t scan_cap_blocks = 0;      // their capacity, in ids
@@ -277,7 +275,6 @@ static void free_scratch(StreamScratch &sc)
     if (sc.aux) (void)hipStreamDestroy(sc.aux);
     if (sc.d_ctl) (void)hipFree(sc.d_ctl);
     if (sc.d_queues) (void)hipFree(sc.d_queues);
-    if (sc.d_queues_split) (void)hipFree(sc.d_queues_split);
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
     if (sc.h_hint) (void)hipHostFree(sc.h_hint);
@@ -375,169 +372,6 @@ static void xcd_shares_update(const mbk_ctx *ctx, StreamScratch &sc)
     }
 }
 
-static bool window_may_touch_ring(const TileArgs &a, double margin);
-
-// Shares of an 8 x 8 grid of the window's pixels still inside after 32 steps and after `probe` steps (host doubles: a
-// scheduling heuristic, results never depend on it).  The deep part runs only when at least `need32` of the pixels pass the
-// first 32 steps (6 us for the many launches that are no deep zoom; up to ~100 us for one that is).
-static void window_alive_shares(const TileArgs &a, uint32_t probe, double need32, double *alive32, double *alive_probe)
-{
-    const uint32_t k = 8;
-    double zr[64], zi[64], cr[64], ci[64];
-    bool in[64];
-    uint32_t n32 = 0, np = 0;
-    for (uint32_t j = 0; j < k; ++j)
-        for (uint32_t i = 0; i < k; ++i) {
-            const uint32_t q = j * k + i;
-            ci[q] = axis_value_host(a.im, a.row0 + (uint32_t)(((uint64_t)(2u * j + 1u) * a.nrows) / (2u * k)));
-            cr[q] = axis_value_host(a.re, a.col0 + (uint32_t)(((uint64_t)(2u * i + 1u) * a.ncols) / (2u * k)));
-            zr[q] = cr[q];
-            zi[q] = ci[q];
-            in[q] = true;
-        }
-    auto run = [&](uint32_t steps) {
-        uint32_t alive = 0;
-        for (uint32_t q = 0; q < k * k; ++q) {
-            if (!in[q]) continue;
-            double x = zr[q], y = zi[q];
-            uint32_t n = 0;
-            for (; n < steps; ++n) {
-                const double t = x * x - y * y + cr[q];
-                y = 2.0 * x * y + ci[q];
-                x = t;
-                if (!(x * x + y * y < 4.0)) break;
-            }
-            zr[q] = x;
-            zi[q] = y;
-            in[q] = n >= steps;
-            alive += in[q] ? 1u : 0u;
-        }
-        return alive;
-    };
-    n32 = run(32u);
-    *alive32 = (double)n32 / (double)(k * k);
-    *alive_probe = *alive32;
-    if (*alive32 < need32 || probe <= 32u) return;
-    np = run(probe - 32u);
-    *alive_probe = (double)np / (double)(k * k);
-}
-
-// The split of deep zooms (csrc/mbk_split.h): classify by a deep centre probe, the blocks with escaping pixels through the
-// lane-refill kernel, the all-alive ones through the units kernel, the bytes by a post-pass.  *taken = false: the launch is
-// not one the split serves (or MBK_OPT_SPLIT = 1 and its host probe does not call the window a boundary-rich deep zoom);
-// the caller goes on as before.
-static int launch_split(mbk_ctx *ctx, TileArgs a, uint32_t nblocks, uint32_t nby, bool cyc, hipStream_t stream, bool *taken)
-{
-    *taken = false;
-    const uint32_t probe = ctx->opt[MBK_OPT_SPLIT_PROBE];
-    if (a.smooth != nullptr || a.counts == nullptr || a.blocks_x % 8u != 0u || a.blocks_x > 2048u || nby > 0xffffu ||
-        a.fast_bx_end == 0u || a.fast_by_end == 0u || ctx->opt[MBK_OPT_GROUP_STEPS] != 16u || nblocks < 16384u ||
-        (uint32_t)a.mrd <= 4u * probe || a.re.step_is_zero || a.im.step_is_zero || a.out_pitch != a.ncols || a.out_col0 != 0u ||
-        a.out_row0 != 0u || window_may_touch_ring(a, 1e-6))
-        return MBK_OK;
-    double alive32 = 0.0, alive_probe = 0.0;
-    window_alive_shares(a, probe, ctx->opt[MBK_OPT_SPLIT] == 1u ? 0.9 : 0.0, &alive32, &alive_probe);
-    // a deep zoom on the boundary: (nearly) nothing leaves within 32 steps -- no light area for the units order to batch --
-    // and a good part leaves before the probe's depth
-    if (ctx->opt[MBK_OPT_SPLIT] == 1u && !(alive32 >= 0.9 && alive32 - alive_probe >= 0.25)) return MBK_OK;
-
-    StreamScratch *sc = nullptr;
-    int rc = get_scratch(ctx, stream, &sc);
-    if (rc != MBK_OK) return rc;
-    const bool overlap = ctx->opt[MBK_OPT_PREPASS_OVERLAP] != 0u;
-    if (!sc->aux) {
-        MBK_HIP(ctx, hipStreamCreateWithFlags(&sc->aux, hipStreamNonBlocking));
-        sc->aux_prio = 1u;
-        for (int k = 0; k < kOrderRing; ++k) {
-            MBK_HIP(ctx, hipEventCreateWithFlags(&sc->ev_cls[k], hipEventDisableTiming));
-            MBK_HIP(ctx, hipEventCreateWithFlags(&sc->ev_done[k], hipEventDisableTiming));
-        }
-    }
-    if (nblocks > sc->order_cap) {
-        MBK_HIP(ctx, hipStreamSynchronize(stream));
-        MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
-        for (int k = 0; k < kOrderRing; ++k) {
-            if (sc->d_order[k]) (void)hipFree(sc->d_order[k]);
-            sc->d_order[k] = nullptr;
-            sc->done_valid[k] = false;
-        }
-        sc->order_cap = 0;
-        for (int k = 0; k < kOrderRing; ++k)
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_order[k], mbk::units_list_words(nblocks) * sizeof(uint32_t)));
-        sc->order_cap = nblocks;
-    }
-    if (!sc->d_queues_split) MBK_HIP(ctx, hipMalloc((void **)&sc->d_queues_split, kOrderRing * sizeof(WorkQueues)));
-    const unsigned k = sc->order_turn++ % (unsigned)kOrderRing;
-    uint32_t *ord = sc->d_order[k];
-    WorkQueues *wq = sc->d_queues_split + k;
-    const size_t n = nblocks;
-    hipStream_t pre = overlap ? sc->aux : stream;
-    if (overlap && sc->done_valid[k]) MBK_HIP(ctx, hipStreamWaitEvent(sc->aux, sc->ev_done[k], 0));
-    MBK_HIP(ctx, hipMemsetAsync(ord + n, 0, 3 * sizeof(uint32_t), pre));            // units side: H count | V units | M
-    MBK_HIP(ctx, hipMemsetAsync(ord + 2u * n + 3u, 0, 3 * sizeof(uint32_t), pre));  // late M | settled H | refill side's count
-    hipLaunchKernelGGL(mbk::classify_split_kernel, dim3((nblocks + 1023u) / 1024u), dim3(1024), 0, pre, a, nblocks, (int32_t)probe, ord);
-    mbk::XcdShares w;
-    const double even[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
-    shares_from_fractions(even, w.cum);
-    a.plan = ord + ((2u * n + 5u + 15u) & ~(size_t)15u);
-    // (the split's lists do not feed the XCD-share controller: its launches are counted so that the ring stays in step)
-    const uint32_t seq = ++sc->xcd_issued;
-    sc->xcd_ring[seq % kShareRing].seq = 0u;
-    hipLaunchKernelGGL(mbk::units_plan_kernel, dim3(1), dim3(1), 0, pre, (const uint32_t *)(ord + n), (const uint32_t *)(ord + 2u * n + 3u), w, 0u,
-                       (uint32_t *)a.plan);
-    hipLaunchKernelGGL(mbk::init_queues_list_kernel, dim3(1), dim3(64), 0, pre, wq, (const uint32_t *)(ord + 2u * n + 5u));
-    MBK_HIP(ctx, hipGetLastError());
-    if (overlap) {
-        MBK_HIP(ctx, hipEventRecord(sc->ev_cls[k], sc->aux));
-        MBK_HIP(ctx, hipStreamWaitEvent(stream, sc->ev_cls[k], 0));
-    }
-    // refill side
-    mbk::PersistArgs q;
-    std::memset(&q, 0, sizeof(q));
-    q.re_start = a.re.start;
-    q.re_step = a.re.step;
-    q.im_start = a.im.start;
-    q.im_step = a.im.step;
-    q.col0 = a.col0;
-    q.row0 = a.row0;
-    q.pitch = a.out_pitch;
-    q.bxn = a.blocks_x;
-    q.nblocks = 0u;           // read from list_count on the device
-    q.total = (uint32_t)a.mrd - 1u;
-    q.livemin = ctx->opt[MBK_OPT_RF_LIVEMIN];
-    q.patience = ctx->opt[MBK_OPT_RF_PATIENCE];
-    q.batch = ctx->opt[MBK_OPT_RF_BATCH];
-    q.counts = a.counts;
-    q.list = ord + n + 3u;
-    q.list_count = ord + 2u * n + 5u;
-    const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-    const uint32_t waves = cus * 4u * ctx->opt[MBK_OPT_RF_WAVES];
-    hipLaunchKernelGGL(mbk::tile_persist_kernel, dim3((waves + 3u) / 4u), dim3(256), 0, stream, q, wq);
-    // units side: counts only (the bytes come from the post-pass), with or without the cycle test
-    uint8_t *bytes = a.bytes;
-    a.bytes = nullptr;
-    a.order = ord;
-    a.ngrid = nblocks;
-    a.order_mid = 0u;
-    a.stamps = nullptr;
-    a.stamp_tag = 0u;
-    const double est = (double)nblocks * alive_probe * 1.3 + 2048.0;
-    uint32_t g = (uint32_t)std::min<double>((double)nblocks, est);
-    g = (std::max(std::max(g, std::min(nblocks, cus * 64u)), 16384u) + 7u) & ~7u;
-    a.unit_stride = g;
-    if (cyc) hipLaunchKernelGGL((mbk::tile_units_kernel<double, 16, true, true, false>), dim3(g), dim3(64), 0, stream, a, 0u);
-    else hipLaunchKernelGGL((mbk::tile_units_kernel<double, 16, false, true, false>), dim3(g), dim3(64), 0, stream, a, 0u);
-    if (bytes) {
-        const uint64_t npx = (uint64_t)a.ncols * a.nrows;
-        hipLaunchKernelGGL(mbk::quantise_kernel, dim3(2048), dim3(256), 0, stream, a.counts, bytes, npx, a.mrd, a.quant_wide, a.quant_rcp);
-    }
-    MBK_HIP(ctx, hipGetLastError());
-    MBK_HIP(ctx, hipEventRecord(sc->ev_done[k], stream));
-    sc->done_valid[k] = true;
-    *taken = true;
-    return MBK_OK;
-}
-
 // Launch the one-wave-per-block kernels ("asm" / "group", fp64 or fp32) for the window described by `a`
 // (a.col0/row0/ncols/nrows, output at a.out_*), optionally behind the heavy-first classify pre-pass.
 // fuse / counts_unwanted / fused: as for launch_scan_t -- partial-result slots (already zeroed on `stream`) to which a kernel
@@ -566,12 +400,6 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     // ... and only where there is light area to batch: the share of the host's 16 x 16 probe pixels of the window that is gone
     // after 4 steps (a deterministic function of the window).  Measured (profiles/r04/units_ab.txt): cfg2 (0.64 light) strict
     // -0.3 % / cycle test +4.7 %, DataChunk (1,0,0) (0.8) +2.1 % / +9.7 %, cfg3 (none) -0.7 % / 0.
-    // The split of deep zooms (mbk_split.h) takes the launches it can serve and that its host probe calls boundary-rich
-    if (order_mode == 3 && wpw == 1u && kernel == MBK_KERNEL_GROUP && !safe && !f32 && ctx->opt[MBK_OPT_SPLIT] != 0u) {
-        bool taken = false;
-        const int rc = launch_split(ctx, a, grid.x, by, cyc, stream, &taken);
-        if (rc != MBK_OK || taken) return rc;
-    }
     double unit_share = 0.0;
     if (units) {
         unit_share = window_heavy_share(a);
@@ -774,7 +602,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
 }
 
 // Can any pixel of the window lie within the ring | |c|^2 - 4 | < 1e-6 ?  (conservative rectangle test)
-static bool window_may_touch_ring(const TileArgs &a, double margin)
+static bool window_may_touch_ring(const TileArgs &a, double margin = 1e-6)
 {
     const double x0 = axis_value_host(a.re, a.col0), x1 = axis_value_host(a.re, a.col0 + a.ncols - 1u);
     const double y0 = axis_value_host(a.im, a.row0), y1 = axis_value_host(a.im, a.row0 + a.nrows - 1u);
@@ -813,7 +641,7 @@ static int launch_refill(mbk_ctx *ctx, const TileArgs &a, bool safe, hipStream_t
     if (icols == 0 || irows == 0) return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, false, stream);
 
     mbk::PersistArgs q;
-    std::memset(&q, 0, sizeof(q));      // (list = nullptr: the blocks of the window in image order)
+    std::memset(&q, 0, sizeof(q));
     q.re_start = a.re.start;
     q.re_step = a.re.step;
     q.im_start = a.im.start;
@@ -1255,7 +1083,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u, /* SPLIT */ 1u, /* SPLIT_PROBE */ 512u};
+        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1778,8 +1606,6 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_PROBE_MID: ok = value >= 2u && value <= 65537u; break;
         case MBK_OPT_PREPASS_OVERLAP: ok = value <= 2u; break;
         case MBK_OPT_CLASSIFY_WG: ok = value >= 64u && value <= 1024u && value % 64u == 0u; break;
-        case MBK_OPT_SPLIT: ok = value <= 2u; break;
-        case MBK_OPT_SPLIT_PROBE: ok = value >= 32u && value <= 65536u; break;
         case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;

@@ -29,15 +29,10 @@ struct PersistArgs {
     uint32_t total;                                // mrd - 1 (>= 1)
     uint32_t livemin, patience, batch;             // refill policy / blocks per pop
     int32_t *counts;
-    // round 5, the split of deep zooms (mbk_split.h): with `list` the kernel works through list[0 .. *list_count) -- entries
-    // (block row << 16) | block column written by classify_split_kernel -- instead of the blocks 0 .. nblocks-1 of the window
-    const uint32_t *list;
-    const uint32_t *list_count;
 };
 
 __global__ __launch_bounds__(256) void tile_persist_kernel(PersistArgs p, WorkQueues *wq)
 {
-    if (p.list) p.nblocks = uniform_u32(*p.list_count);   // (known on the device only; init_queues_list_kernel read the same word)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t home = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u;
     constexpr uint32_t kFar = 0x40000000u;  // all relative clock offsets stay below 2^30
@@ -84,15 +79,9 @@ __global__ __launch_bounds__(256) void tile_persist_kernel(PersistArgs p, WorkQu
                     }
                     blk_left = got - 1u;
                 }
-                if (p.list) {
-                    const uint32_t e = uniform_u32(p.list[blk]);
-                    blk_col = (e & 0xffffu) * 8u;
-                    blk_row = (e >> 16) * 8u;
-                } else {
-                    const uint32_t by = blk / p.bxn;
-                    blk_col = (blk - by * p.bxn) * 8u;
-                    blk_row = by * 8u;
-                }
+                const uint32_t by = blk / p.bxn;
+                blk_col = (blk - by * p.bxn) * 8u;
+                blk_row = by * 8u;
                 blk_pos = 0;
             }
             const unsigned long long free_lanes = ~live;

@@ -34,12 +34,6 @@ __global__ __launch_bounds__(64) void init_queues_kernel(WorkQueues *w, uint32_t
     w->q[threadIdx.x].next = queue_lo(nblocks, threadIdx.x);
 }
 
-// The same for a list whose length exists on the device only (mbk_split.h)
-__global__ __launch_bounds__(64) void init_queues_list_kernel(WorkQueues *w, const uint32_t *count)
-{
-    w->q[threadIdx.x].next = queue_lo(*count, threadIdx.x);
-}
-
 // Per-wave view of the queues: the queue it is currently draining and that queue's end.
 struct Popper {
     uint32_t cq;      // current queue (wave-uniform)

@@ -321,13 +321,6 @@ enum mbk_option {
                               L + 1 runs beside the tile kernel of launch L (MBK_OPT_PREPASS_OVERLAP); a 1024-thread workgroup needs
                               16 free wave slots on ONE CU at once, which a chip full of single-wave workgroups offers only in its
                               drain */
-    MBK_OPT_SPLIT,         /* order 3, fp64: the split of deep zooms (csrc/mbk_split.h) -- blocks whose centre pixel is still inside after
-                              MBK_OPT_SPLIT_PROBE steps run one wave per block as before, all other (regular) blocks through the
-                              lane-refill kernel (MBK_OPT_RF_*): 0 off, [1] where the host's probe of the window finds a deep
-                              zoom on the boundary (>= 90 % of 64 pixels inside after 32 steps, >= 25 % of them gone by the
-                              probe's depth), 2 wherever the launch can be served (tests).  Changes by which of two exact
-                              routines a block is computed, never what is stored */
-    MBK_OPT_SPLIT_PROBE,   /* depth of the split's centre probe: 32 .. 65536 [512]; the launch needs mrd > 4 x this */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

@@ -16,7 +16,7 @@ combos = [("scan", "f64"), ("default", "f64"), ("group", "f64"), ("asm", "f64"),
 OPTION_CHOICES = {"scan_waves": [1, 2, 8], "scan_xcd_map": [0, 1], "scan_col_period": [0, 1, 4], "group_steps": [4, 8, 16, 32], "scan_inline": [0, 1],
                   "exact_steps": [0, 3, 8, 20], "order": [0, 1, 2, 3], "xcd_balance": [0, 1, 2], "units_min_light": [0, 32768], "heavy_share": [0, 655, 65536], "waves_per_wg": [1, 2, 4],
                   "cycle_detect": [0, 1], "probe_mid": [2, 6, 65537], "prepass_overlap": [0, 1, 2], "probe_steps": [2, 32, 200], "exact_long": [0, 4, 8],
-                  "m_late": [0, 4, 8, 12], "h_settled": [0, 5, 6, 9], "split": [0, 1, 2], "split_probe": [32, 64, 512], "classify_wg": [64, 256, 1024]}
+                  "m_late": [0, 4, 8, 12], "h_settled": [0, 5, 6, 9], "classify_wg": [64, 256, 1024]}
 t0 = time.time(); n = 0; px = 0
 dev = None
 while time.time() - t0 < budget:
@@ -53,7 +53,7 @@ while time.time() - t0 < budget:
         span_r, span_i, big = rs.uniform(0.05, 0.4), rs.uniform(0.8, 3.2), True
     w, h = (int(rs.randint(200, 1400)), int(rs.randint(200, 1100))) if big else (int(rs.randint(1, 200)), int(rs.randint(1, 200)))
     mrd = int(rs.choice([2, 3, 4, 5, 6, 8, 9, 10, 16, 17, 18, 24, 25, 26, 33, 41, 57, 100, 257, 1000] + ([] if big else [4000, 20000])))
-    if kind in (2, 4, 6) and rs.rand() < 0.35:      # what the units kernel and the split of deep zooms serve: >= 16 384 blocks, block
+    if kind in (2, 4, 6) and rs.rand() < 0.35:      # what the units kernel serves: >= 16 384 blocks, block
         w, h = 64 * int(rs.randint(16, 22)), int(rs.randint(1024, 1300))   # columns a multiple of 8, on the boundary of the set
         mrd = int(rs.choice([150, 300, 700, 2500]))
         span_r = 10.0 ** rs.uniform(-6, -0.5); span_i = span_r * rs.uniform(0.5, 2.0)

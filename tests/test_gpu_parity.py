@@ -417,7 +417,6 @@ OPTION_MATRIX = [
     ("default", {"m_late": 31}), ("group", {"order": 3, "m_late": 12, "units_min_light": 0}), ("default", {"m_late": 65536, "xcd_balance": 1, "cycle_detect": 0}),
     ("group", {"order": 3, "h_settled": 0}), ("group", {"order": 3, "h_settled": 1, "m_late": 0, "xcd_balance": 2, "units_min_light": 0}),
     ("default", {"h_settled": 30}), ("group", {"order": 3, "h_settled": 9, "cycle_detect": 0}),
-    ("default", {"split": 0}), ("group", {"split": 2, "split_probe": 32}), ("default", {"split": 2, "split_probe": 100, "cycle_detect": 0}),
     ("default", {"prepass_overlap": 2, "classify_wg": 256}), ("group", {"classify_wg": 64, "m_late": 4}),
 ]
 
@@ -499,64 +498,6 @@ def test_units_order_every_output_set_and_shape(oracle):
                             assert np.array_equal(got, oc), (tag, int((got != oc).sum()))
                         if want_b:
                             assert np.array_equal(db.cpu().numpy().reshape(nrows, ncols), ob), tag
-
-
-def test_split_of_deep_zooms_is_bit_exact(oracle):
-    """The split of deep zooms (csrc/mbk_split.h, MBK_OPT_SPLIT): blocks whose centre is still inside after the probe run on the
-    units kernel, every other regular block through the lane-refill kernel, the bytes by a post-pass.  Forced (split = 2) with
-    shallow probes on views that exercise both sides: a deep zoom, the seahorse valley (many never-escaping pixels on the
-    refill side), a ragged last block row, a window with an offset inside a larger view, a view that is all alive (refill list
-    empty) and one that is all gone (units list = the irregular blocks only); cycle test on / off; the host API (counts +
-    bytes + statistics) and device buffers on a caller's stream, counts only and bytes too.  And split = 1 (the default)
-    picks the deep zoom by itself and leaves the full-set view alone."""
-    import torch
-    from distributedmandelbrot_amd import MandelbrotDevice
-    cases = [
-        (View(-0.743648, 0.131820, 1e-5, 1e-5, 1024, 1024), None, 700, 64),
-        (View(-0.755, 0.10, 0.02, 0.02, 1024, 1024), None, 300, 32),
-        (View(-0.743648, 0.131820, 1e-5, 1e-5, 1024, 1003), None, 500, 100),             # ragged last block row -> units side
-        (View(-0.7437, 0.1318, 2e-4, 2e-4, 2048, 2048), (512, 256, 1024, 1536), 400, 48),  # window inside a larger view
-        (View(-0.2, -0.1, 0.2, 0.2, 1024, 1024), None, 200, 32),                          # all alive: nothing to refill
-        (View(0.40, 0.40, 0.2, 0.2, 1024, 1024), None, 200, 32),                          # all gone within the probe
-    ]
-    with MandelbrotDevice(0) as dev:
-        dev.set_option("split", 2)
-        for cyc in (1, 0):
-            dev.set_option("cycle_detect", cyc)
-            for view, window, mrd, probe in cases:
-                dev.set_option("split_probe", probe)
-                col0, row0, ncols, nrows = window if window else (0, 0, view.width, view.height)
-                oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd, window=window)
-                c, b, st = dev.compute_view(view, mrd, window=window, kernel="group")
-                tag = (view, window, mrd, probe, cyc)
-                assert np.array_equal(c, oc), (tag, int((c != oc).sum()))
-                assert np.array_equal(b, ob), tag
-                assert st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum()), tag
-                _, hb, st2 = dev.compute_view(view, mrd, window=window, want_counts=False)      # the default selector, bytes only
-                assert np.array_equal(hb, ob) and st2.pixel_iterations == total, tag
-                for want_b in (False, True):
-                    dc = torch.full((nrows * ncols,), -9, dtype=torch.int32, device="cuda:0")
-                    db = torch.full((nrows * ncols,), 77, dtype=torch.uint8, device="cuda:0") if want_b else None
-                    torch.cuda.synchronize()
-                    for _ in range(3):      # three launches back to back: the three dispatch lists of the stream in turn
-                        dev.launch_view(view, mrd, window=window, d_counts=dc.data_ptr(), d_bytes=db.data_ptr() if want_b else 0,
-                                        stream=torch.cuda.current_stream().cuda_stream, kernel="group")
-                    torch.cuda.synchronize()
-                    assert np.array_equal(dc.cpu().numpy().reshape(nrows, ncols), oc), (tag, want_b)
-                    if want_b:
-                        assert np.array_equal(db.cpu().numpy().reshape(nrows, ncols), ob), tag
-    # the default (split = 1): a deterministic function of the window.  Timing tells which path ran only indirectly, so compare
-    # results with the split forced off: identical either way, on the deep zoom and on the full set
-    for view, mrd in ((View(-0.743648, 0.131820, 1e-5, 1e-5, 2048, 2048), 3000), (View(-2.0, -1.5, 3.0, 3.0, 2048, 2048), 3000)):
-        got = []
-        for split in (1, 0):
-            with MandelbrotDevice(0) as dev:
-                dev.set_option("split", split)
-                c, b, st = dev.compute_view(view, mrd)
-                got.append((c, b, st.pixel_iterations, st.never_pixels))
-        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]) and got[0][2:] == got[1][2:]
-        oc, ob, total = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd)
-        assert np.array_equal(got[0][0], oc) and got[0][2] == total
 
 
 def test_xcd_shares_follow_solitary_strict_launches():
