@@ -390,6 +390,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     a.perm_mul = order_mode == 1 ? coprime_multiplier(grid.x) : 1u;
     a.order = nullptr;
     int order_slot = -1;
+    bool mid_first = false;
     StreamScratch *order_sc = nullptr;
     // order 3 = "units" (mbk_units.h): the light blocks of eight neighbouring block columns are ONE workgroup.  Where the
     // units kernel cannot serve a launch (outputs, widths, step counts it has no form for) the launch takes order 2.
@@ -516,8 +517,13 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                                a.stamps ? 1u : 0u);
         } else {
         MBK_HIP(ctx, hipMemsetAsync(cursors, 0, 3 * sizeof(uint32_t), pre));
+        // the middle class: MBK_OPT_PROBE_MID's (dispatched between heavy and light) or, without one, MBK_OPT_M_LATE's
+        // (order 3 only: boundary blocks whose centre escapes at step >= m_late, dispatched first)
+        mid_first = order_mode == 3 && ctx->opt[MBK_OPT_PROBE_MID] > probe_steps && ctx->opt[MBK_OPT_M_LATE] >= 2u &&
+                    ctx->opt[MBK_OPT_M_LATE] <= probe_steps;
         hipLaunchKernelGGL(mbk::classify_blocks_kernel, dim3((grid.x + 1023u) / 1024u), dim3(1024), 0, pre, a,
-                           grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)ctx->opt[MBK_OPT_PROBE_MID], ord, cursors);
+                           grid.x, 8u * wpw, (int32_t)probe_steps, (int32_t)(mid_first ? ctx->opt[MBK_OPT_M_LATE] : ctx->opt[MBK_OPT_PROBE_MID]),
+                           ord, cursors);
         }
         if (overlap) {
             MBK_HIP(ctx, hipEventRecord(sc->ev_cls[k], sc->aux));
@@ -527,7 +533,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         order_sc = sc;
         a.order = ord;
         a.ngrid = grid.x;
-        a.order_mid = ctx->opt[MBK_OPT_PROBE_MID] <= probe_steps ? 1u : 0u;
+        a.order_mid = mid_first ? 2u : (ctx->opt[MBK_OPT_PROBE_MID] <= probe_steps ? 1u : 0u);
     }
     // MBK_OPT_WAVE_LIMIT: unused dynamic LDS caps the resident waves per SIMD (single-wave workgroups only)
     const uint32_t lds = wpw == 1u ? ctx->wave_limit_lds[ctx->opt[MBK_OPT_WAVE_LIMIT] & 7u] : 0u;

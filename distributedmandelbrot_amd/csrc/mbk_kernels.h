@@ -57,7 +57,8 @@ struct TileArgs {
                            // the layout); an entry is (block row << 16) | workgroup column -- the host offers it only
                            // when both fit 16 bits
     uint32_t ngrid;        // with `order`: the grid size (= list length); the counters sit at order[ngrid .. ngrid + 3)
-    uint32_t order_mid;    // with `order`: 1 = a middle class was built (MBK_OPT_PROBE_MID <= probe depth)
+    uint32_t order_mid;    // with `order`: 1 = a middle class was built (MBK_OPT_PROBE_MID <= probe depth), dispatched between
+                           // the heavy and the light blocks; 2 = built from MBK_OPT_M_LATE and dispatched FIRST
     uint32_t unit_stride;  // kernel "units" (mbk_units.h): the grid size G; workgroup j takes units j, j + G, ...
     uint32_t stamp_tag;    // kernel "units": 16-bit launch number written into the top of every time stamp
     const uint32_t *plan;  // kernel "units": the shares of the eight XCDs (units_plan_kernel; layout in mbk_units.h)
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     // Dispatch order != image order when an order list is given (heavy-first, classify_blocks_kernel)
     // or perm_mul != 1 (multiplicative permutation, coprime to the grid size).
     uint32_t bx, by;
-    uint32_t n_heavy = 0u;
+    uint32_t n_heavy = 0u, heavy_lo = 0u;
     if (p.order) {
         // classes (classify_blocks_kernel): heavy at the front of the list, light filled in from its back, and -- only
         // when a middle class was built (p.order_mid) -- that class in a list of its own right behind the three
@@ -286,7 +287,15 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
         // round trips (arguments, then entry + count) instead of four -- a light block lives for little else.
         const uint32_t j = blockIdx.x;
         uint32_t e;
-        if (p.order_mid) {
+        if (p.order_mid == 2u) {
+            // round 5, "M late first" (mbk_units.h has the why): the middle class -- boundary blocks whose centre escapes
+            // late, among them the few that hold a never-escaping pixel and run as long as an interior block -- opens the
+            // dispatch order instead of sitting between the heavy and the light blocks
+            n_heavy = p.order[p.ngrid];
+            const uint32_t n_mid = p.order[p.ngrid + 2u];
+            e = j < n_mid ? p.order[p.ngrid + 3u + j] : (j < n_mid + n_heavy ? p.order[j - n_mid] : p.order[j]);
+            heavy_lo = n_mid;
+        } else if (p.order_mid) {
             n_heavy = p.order[p.ngrid];
             const uint32_t n_mid = p.order[p.ngrid + 2u];
             e = (j >= n_heavy && j < n_heavy + n_mid) ? p.order[p.ngrid + 3u + (j - n_heavy)] : p.order[j];
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     }
     const uint32_t wcol = bx * (blockDim.x >> 6) + wave;  // one 8x8 block per wave
     // the blocks the heavy-first probe put at the front of the dispatch order take the 16-step groups
-    const bool long_groups = kGroup >= 16 && (!p.order || blockIdx.x < n_heavy);   // wave-uniform
+    const bool long_groups = kGroup >= 16 && (!p.order || (blockIdx.x >= heavy_lo && blockIdx.x < heavy_lo + n_heavy));   // wave-uniform
     const bool interior = wcol < p.fast_bx_end && by < p.fast_by_end;                        // wave-uniform
     block_pixel<T, kFmaDouble, kGroup, kCycle>(p, wcol * 8u, by * 8u, lane & 7u, lane >> 3, long_groups, interior);
 }
