@@ -8,8 +8,8 @@ kernel generates its coordinates itself and writes int32 escape indices to a res
 (nothing crosses PCIe inside the timed region).  Workload: BASELINE.json configs[1] ("cfg2"): 4096x4096
 samples of the full set (centre -0.5+0i, span 3.0), max_iter (mrd) = 1000, fp64.
 
-N = 1 (the contract's headline): one cfg2 tile per step, launches back to back on one stream, HIP events
-around every launch (`--shard own`).
+N = 1 (the contract's headline): one cfg2 tile per step, launches back to back on one stream, one pair of HIP
+events around the timed region (`--shard own`).
 
 N > 1: `python bench.py --gpus N` starts its own N ranks (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_* in the environment, exactly what `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
@@ -58,7 +58,13 @@ in config.cycle_test); the same K steps with the default ON are timed right afte
 reported as the extra object `cycle_detection` (reference-equivalent rate, ms per step, speed-up).
 `--opt cycle_detect=1` moves the test into the headline, labelled as such.
 
-Two more extra objects at N = 1, both outside `value` (SURVEY.md 8d "reported beside it"):
+`output_verified` (round 5): sha256 of the int32 counts the LAST TIMED launch wrote (one D2H after the timed region) and
+the two totals against the CPU oracle's, committed in tests/golden/bench_outputs.json -- the number on the line belongs to
+the reference's output inside this very run; the cycle-test leg carries its own.  `configs` (round 5, the default N = 1
+line only): a short strict leg of every other single-GPU BASELINE config -- cfg3 (2 launches), cfg5 (3), DataChunk (1,0,0)
+(20), cfg4 as one 16 384 x 1 024 band in fp32 (2) -- each with value, ms_per_step, roofline.frac and output_verified.
+
+More extra objects at N = 1, all outside `value` (SURVEY.md 8d "reported beside it"):
 `end_to_end` -- a whole level of the reference's pyramid (level 16, mrd 1024: 256 DataChunk tiles) through the
 host-buffer API, i.e. kernel + quantise + statistics + D2H into pinned memory: tiles/s synchronous, with two tiles
 in flight, and with uniform tiles not copied (what the worker does); kernel median / mean / max, D2H mean;
@@ -341,7 +347,7 @@ def verify_output(name, d_counts, pixel_iterations, never_pixels, view, mrd, pre
             "golden": f"tests/golden/bench_outputs.json['{name}'] (CPU oracle, {g['oracle']})"}
 
 
-def extra_configs(dev, torch, gpu_index, device_info):
+def extra_configs(dev, torch, gpu_index, device_info, ramp_ms=150.0):
     """Short strict legs (cycle test off, library defaults otherwise) of the other single-GPU BASELINE configs, so that the
     one command the driver times shows every one of them: per config `value`, `ms_per_step`, `roofline.frac` and
     `output_verified` (the timed launches' own buffer against the oracle's hash).  Not part of the headline `value`."""
@@ -365,6 +371,10 @@ def extra_configs(dev, torch, gpu_index, device_info):
                 else:
                     dev.launch_view(view, mrd, window=window, d_counts=d_counts.data_ptr(), stream=stream.cuda_stream, precision=precision)
 
+            t_ramp = time.perf_counter()        # clock pre-conditioning, as for the headline (--ramp-ms): the legs before this
+            while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:   # one left the GPU idle or on another kind of load
+                launch()
+                torch.cuda.synchronize()
             for _ in range(warm):
                 launch()
             torch.cuda.synchronize()
@@ -384,7 +394,7 @@ def extra_configs(dev, torch, gpu_index, device_info):
             out[name] = {
                 "workload": desc + (f"; rows {row0}..{row0 + nrows - 1} of it as one launch" if window else "")
                             + ("; int32 counts + float64 nu to resident HBM" if smooth else "; int32 counts to resident HBM"),
-                "dtype": precision, "cycle_test": "off (every iteration executed)", "steps": steps, "warmup": warm,
+                "dtype": precision, "cycle_test": "off (every iteration executed)", "steps": steps, "warmup": warm, "clock_ramp_ms": ramp_ms,
                 "value": st.pixel_iterations * steps / wall / 1e9, "unit": "G pixel-iterations/s", "ms_per_step": wall / steps * 1e3,
                 "pixel_iterations_per_step": st.pixel_iterations,
                 "roofline": {"bound": "fp64_valu" if precision == "f64" else "fp32_valu", "achieved": achieved, "peak": peak,
@@ -1039,7 +1049,7 @@ def main():
             rec["queue_job"] = queue_job_single(args, rec["value"])
             try:
                 dev.set_option("cycle_detect", 0)
-                rec["configs"] = extra_configs(dev, torch, gpu_index, device_info)
+                rec["configs"] = extra_configs(dev, torch, gpu_index, device_info, ramp_ms=args.ramp_ms if args.ramp_ms > 0 else 0.0)
             except Exception as e:   # noqa: BLE001
                 rec["configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not fake:

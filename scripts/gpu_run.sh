@@ -19,6 +19,7 @@
 #   pmc          rocprofv3 --pmc passes (cfg2 with the source hash, cfg3)
 #   power        power / clock traces
 #   e2e          level rate, worker end to end
+#   (round 5) fill | pmccyc:NAME=V | gaps:W:OPT+OPT | traceopt:W:OPT+OPT[:args] | extprobe | unitstrace:W,cycle,m_late,h_settled ...
 set -u
 TAG=${1:?tag}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
