@@ -596,6 +596,12 @@ def main():
         # periodic orbits retired early) is timed in the same run as the extra object "cycle_detection".
         if "cycle_detect" not in options:
             dev.set_option("cycle_detect", 0)
+        # MBK_OPT_XCD_BALANCE is opt-in since round 5 (library default 0: it helps solitary launches without the cycle test
+        # only, +0.7..1.2 %, i.e. this leg and nothing a worker runs).  The strict headline leg of the one-tile-per-step mode
+        # asks for it -- stated in config.xcd_balance -- and it is switched off again before every other leg.
+        xcd_for_headline = own_mode and "xcd_balance" not in options and not options.get("cycle_detect", 0)
+        if xcd_for_headline:
+            dev.set_option("xcd_balance", 1)
         for k, v in options.items():
             dev.set_option(k, v)
         device_info = dev.info()
@@ -787,6 +793,8 @@ def main():
         else:
             kernel_ms_region = None
             kernel_ms = [a.elapsed_time(b) for a, b in events] if events else [elapsed / args.steps * 1e3]
+        if xcd_for_headline:
+            dev.set_option("xcd_balance", 0)     # the library default for every leg that follows
 
     # N > 1, strong-scaling modes: the SAME job on ONE GPU, timed in this very run.  N = 1 defaults
     # to one tile per step (`--shard own`: the contract's headline), N > 1 to the tile queue, whose single-GPU rate is
@@ -915,8 +923,10 @@ def main():
                "fake_backend": fake, "device": device_info.get("name"), "compute_units": cus, "clock_mhz": mhz,
                "cycle_leg_error": cyc_err,
                "occupancy_api_wg_per_cu": device_info.get("scan_occupancy"),
-               "xcd_balance": (f"{options['xcd_balance']} (--opt)" if "xcd_balance" in options else
-                               "0 (library default; opt-in since round 5: with the round-5 dispatch order it is worth +0.2 % on this leg)"),
+               "xcd_balance": ("1 for this leg only, set by bench.py: MBK_OPT_XCD_BALANCE is opt-in (library default 0) -- it follows "
+                               "solitary launches without the cycle test, i.e. this leg; every other leg of this line and every worker "
+                               "path runs the even deal" if (not fake and xcd_for_headline) else
+                               (f"{options['xcd_balance']} (--opt)" if "xcd_balance" in options else "0 (library default)")),
                "xcd_shares": xcd_after_timed,
                "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
                            ("bench.py self-launch" if "MBK_BENCH_RUN_ID" in os.environ else "single process"),

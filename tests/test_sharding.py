@@ -408,7 +408,7 @@ def test_real_bench_default_line_pins_its_outputs_and_shows_every_config():
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["output_verified"]["verified"] is True, rec["output_verified"]
     assert rec["cycle_detection"]["output_verified"]["verified"] is True
-    assert rec["config"]["xcd_balance"].startswith("0 (library default")
+    assert rec["config"]["xcd_balance"].startswith("1 for this leg only")
     cfgs = rec["configs"]
     assert set(cfgs) == {"cfg3", "cfg5", "chunk_l1", "cfg4_band"}, cfgs.get("error")
     for name, c in cfgs.items():
