@@ -23,7 +23,7 @@ a few gathered Python objects, on gloo (`--control nccl` exists to A/B that choi
                 (4096x4096) tiles covering the workload's view at grid-times finer pitch (default 8 x 8 = 64 tiles:
                 far exterior, boundary and all-interior tiles mixed, cost ratio > 100x).  Every rank pulls ticket
                 numbers from ONE cursor in shared memory (sharding.SharedCursor), ticket t = tile t mod T of step
-                t div T, two tiles in flight per GPU, tickets running on across steps (no barrier between steps).
+                t div T, four tiles in flight per GPU, tickets running on across steps (no barrier between steps).
                 Rank 0 checks that every ticket was taken exactly once (`tiles_exactly_once`) and reports
                 `tiles_per_rank`, the ranks' finish times and `ranks_seen` (host, pid, GPU name, PCI bus id of
                 every rank: there is no RCCL to ask whether N distinct GPUs took part).
@@ -66,7 +66,7 @@ line only): a short strict leg of every other single-GPU BASELINE config -- cfg3
 
 More extra objects at N = 1, all outside `value` (SURVEY.md 8d "reported beside it"):
 `end_to_end` -- a whole level of the reference's pyramid (level 16, mrd 1024: 256 DataChunk tiles) through the
-host-buffer API, i.e. kernel + quantise + statistics + D2H into pinned memory: tiles/s synchronous, with two tiles
+host-buffer API, i.e. kernel + quantise + statistics + D2H into pinned memory: tiles/s synchronous, with two / four tiles
 in flight, and with uniform tiles not copied (what the worker does); kernel median / mean / max, D2H mean;
 `queue_job` -- the N > 1 default job (--shard queue) run on this one GPU, i.e. the same-mode N = 1 point of the
 scaling curve.

@@ -28,7 +28,7 @@ Differences from the reference worker, all wire-compatible:
     lease table, so there is no RCCL and no GPU<->GPU traffic;
   * `run_pipelined` (what run_farm runs per GPU): the same two exchanges per tile, but overlapped --
     while tile n is on the GPU, tile n+1 is being leased and tile n-1 is being sent by a sender thread
-    (two tiles in flight on the device: mbk_datachunk_submit / mbk_wait); the reference is strictly
+    (up to MBK_SLOTS = 4 tiles in flight on the device: mbk_datachunk_submit / mbk_wait); the reference is strictly
     lease -> compute -> send (WorkerCUDA.py:111-176);
   * there is no CPU fallback: without libmbk_hip.so and a gfx950 GPU, process_workload raises.
 """
@@ -501,7 +501,7 @@ def run_farm(addr: str, port: int, devices: Optional[Sequence[int]] = None,
              log: Callable[..., None] = print, max_tiles: Optional[int] = None, senders: int = 2,
              native: bool = False) -> List[int]:
     """One feeder thread per GPU until the Distributer answers 0x11.  Each feeder is `run_pipelined`
-    (lease / compute / send overlapped, two tiles in flight on its GPU) or, with native=True, `run_native` (the
+    (lease / compute / send overlapped, four tiles in flight on its GPU) or, with native=True, `run_native` (the
     same loop inside libmbk_hip.so; `max_tiles` is then split evenly over the feeders up front); with
     `make_compute(device_index)` -- a per-thread compute function, used by the CPU tests -- it is the serial
     do_workload_single loop.  Returns the number of tiles each feeder completed."""
