@@ -1648,7 +1648,7 @@ int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value)
     return MBK_OK;
 }
 
-// The share arithmetic of the units kernel on the host (no device, no context): the very functions units_plan_kernel and
+// The share arithmetic of the units kernel on the host (no device, no context): the very functions classify_units_kernel and
 // tile_units_kernel call, for the CPU tests.
 static void shares_from_fractions(const double *f, uint32_t *cum)
 {

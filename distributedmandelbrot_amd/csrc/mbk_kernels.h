@@ -61,7 +61,7 @@ struct TileArgs {
                            // the heavy and the light blocks; 2 = built from MBK_OPT_M_LATE and dispatched FIRST
     uint32_t unit_stride;  // kernel "units" (mbk_units.h): the grid size G; workgroup j takes units j, j + G, ...
     uint32_t stamp_tag;    // kernel "units": 16-bit launch number written into the top of every time stamp
-    const uint32_t *plan;  // kernel "units": the shares of the eight XCDs (units_plan_kernel; layout in mbk_units.h)
+    const uint32_t *plan;  // kernel "units": the shares of the eight XCDs (units_plan; layout in mbk_units.h)
     unsigned long long *stamps;  // kernel "units", may be null: pinned host memory for this launch's time stamps
     int32_t *counts;      // may be null
     uint8_t *bytes;       // may be null

@@ -103,8 +103,8 @@ __device__ __forceinline__ int32_t probe_settling(double cr, double ci, int32_t 
 }
 
 // counters[0..3): H, V units, M; extra[0..3): late M, settled H, a ticket.  With `plan` the workgroup that finishes last turns
-// the counts into the XCD shares itself (units_plan: what units_plan_kernel does in a launch of its own) and clears the six
-// words for the next launch that uses them -- the pre-pass is then ONE kernel instead of fill + classify + plan, three
+// the counts into the XCD shares itself (units_plan: round 4 ran it in a one-thread kernel of its own) and clears the six words for the
+// next launch that uses them -- the pre-pass is then ONE kernel instead of fill + classify + plan, three
 // dependent launches of a few microseconds each that sit between two tile kernels once a launch no longer ends in a long drain
 // (profiles/r05/gaps_*.txt).  The caller zeroes the six words once, when it allocates them.
 __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32_t nregions, int32_t probe_steps,
@@ -181,12 +181,12 @@ __global__ __launch_bounds__(1024) void classify_units_kernel(TileArgs p, uint32
 // The hardware deals workgroup ids to the XCDs in turn (id mod 8 -- profiles/microbench/units_trace.hip read XCC_ID), every XCD
 // works through its own ids, and the XCDs of one chip do not run at one speed: equal shares end 2-10 % apart and the launch
 // lasts as long as its slowest XCD (profiles/NOTES.md 2b).  Atomics across XCDs are far too slow to rebalance at run time
-// (units_pool_ab.txt), so the shares themselves are uneven: XCD x takes h[x] entries of the H list, then l[x] of the light
-// list (M entries, then V units).  Workgroup id 8 j + x finds its unit without atomics: entry 8 j + x while j is below the
+// (units_pool_ab.txt), so the shares themselves are uneven: XCD x takes h[x] entries of the front list (late M, H, settled H),
+// then l[x] of the light list (M entries, then V units).  Workgroup id 8 j + x finds its unit without atomics: entry 8 j + x while j is below the
 // smallest share (the even deal, nearly all ids), and behind that the rest of the list in one contiguous piece per XCD
 // (entry base[x] + j).  The host sets the H fractions from what earlier launches on the stream reported (mbk_api.hip: the time at
 // which every XCD dealt its last ids, kStampTail plain stores per XCD into pinned memory); the counts are known only on the
-// device, so a one-thread kernel behind classify turns fractions into shares.  Which XCD computes a block changes when it
+// device, so the last workgroup of classify turns fractions into shares.  Which XCD computes a block changes when it
 // is computed, never what is stored.
 constexpr uint32_t kStampTail = 8;                      // ids per XCD, from the end, that leave a time stamp
 constexpr uint32_t kStampWords = 8u + 8u * kStampTail;  // per launch: first id of every XCD, then the tails
@@ -241,13 +241,6 @@ __host__ __device__ __forceinline__ bool units_lookup(uint32_t u, uint32_t hmin,
     if (!is_h && k >= l_x) return false;
     i = is_h ? (j < hmin ? u : hbase_x + j) : (k < lmin ? 8u * k + x : lbase_x + k);
     return true;
-}
-
-__global__ void units_plan_kernel(const uint32_t *counters, const uint32_t *late, XcdShares w, uint32_t stamps, uint32_t *plan)
-{
-    // (late = order + 2n + 3: the counts of late M entries, which open the front list, and of settled H entries, which end it)
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        units_plan(counters[0] + late[0] + late[1], counters[1], counters[2], w.cum, stamps, plan, late[0], late[1]);   // (split path, microbenchmarks)
 }
 
 // The eleven words of the plan a workgroup of XCD x needs, with scalar loads issued together (scalar_load_u32's comment)
