@@ -757,14 +757,21 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
 
     mbk::ScanArgs s;
     std::memset(&s, 0, sizeof(s));
-    s.stride_by = std::min(wmax / a.blocks_x, nby);
+    // Row strips (mbk_scan.h): in the finish-in-place form a wave's region is 64 x 1 pixels instead of an 8x8 block, so that
+    // every store instruction writes one contiguous piece of a row; the fields below then count strips and rows.  Not for
+    // narrow windows (the ragged last strip of a row runs with idle lanes).
+    const bool strip = inline_todo && ctx->opt[MBK_OPT_SCAN_STRIP] != 0u && a.ncols >= 512u;
+    const uint32_t regions_x = strip ? (a.ncols + 63u) / 64u : a.blocks_x, regions_y = strip ? a.nrows : nby, region_h = strip ? 1u : 8u;
+    s.strip = strip ? 1u : 0u;
+    s.strips_x = regions_x;
+    s.stride_by = std::min(wmax / regions_x, regions_y);
     // (pass 1 addresses a run of blocks through a 32-bit lane offset that advances by this much per block)
-    if ((uint64_t)s.stride_by * 8u * a.out_pitch * 4u >= (1ull << 31)) return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
-    const uint32_t w1 = s.stride_by * a.blocks_x;
+    if ((uint64_t)s.stride_by * region_h * a.out_pitch * 4u >= (1ull << 31)) return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
+    const uint32_t w1 = s.stride_by * regions_x;
     s.nblocks = nblocks;
     // XCD-aware column order (profiles/microbench/light_path.hip: the 8x8 store pattern of a 4096^2 int32 tile
     // takes 25.6 us in image order -- each 128-byte line is written by four XCDs -- and 12.9 us with it)
-    s.xcd_map = (ctx->opt[MBK_OPT_SCAN_XCD_MAP] != 0u && a.blocks_x % 32u == 0u) ? 1u : 0u;
+    s.xcd_map = (!strip && ctx->opt[MBK_OPT_SCAN_XCD_MAP] != 0u && a.blocks_x % 32u == 0u) ? 1u : 0u;
     // column jump: ~5/16 of the width, a multiple of 32 columns when the XCD map is on (keeps its grouping).  It
     // spreads the unfinished blocks of a window over the lists; where nothing is expected to be unfinished (the
     // finish-in-place form) a wave keeps its column: the jumps cost the all-exterior tile 3 of its 23 us
@@ -773,10 +780,10 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     if (s.xcd_map) s.col_jump = 32u * (((a.blocks_x / 32u) * 5u / 16u) | 1u);
     else s.col_jump = std::max(1u, a.blocks_x * 5u / 16u);
     if (s.col_jump >= a.blocks_x) s.col_jump = 0u, s.col_period = 0u;
-    s.fast_bx_end = a.ncols / 8u;
-    // block rows whose imaginary coordinates all come from the regular formula (the asm computes them that way)
+    s.fast_bx_end = a.ncols / (strip ? 64u : 8u);
+    // block rows (strips: rows) whose imaginary coordinates all come from the regular formula (the asm computes them that way)
     const uint32_t im_n = a.im.n - (axis_end_is_regular(a.im) ? 0u : 1u);
-    s.fast_by_end = std::min(a.nrows / 8u, im_n > a.row0 ? (im_n - a.row0) / 8u : 0u);
+    s.fast_by_end = std::min(a.nrows / region_h, im_n > a.row0 ? (im_n - a.row0) / region_h : 0u);
     s.qtab = 0u;
     if (a.bytes && a.mrd > 0)
         for (uint32_t k = 1; k <= 4u; ++k)
@@ -1089,7 +1096,8 @@ int mbk_create(int device, mbk_ctx **out)
         /* SCAN_WAVES */ 8u, /* SCAN_XCD_MAP */ 1u, /* SCAN_COL_PERIOD */ 4u, /* HEAVY_SHARE */ 655u,
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
-        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u};
+        /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u,
+        /* SCAN_STRIP */ 1u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1612,6 +1620,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_PROBE_MID: ok = value >= 2u && value <= 65537u; break;
         case MBK_OPT_PREPASS_OVERLAP: ok = value <= 2u; break;
         case MBK_OPT_CLASSIFY_WG: ok = value >= 64u && value <= 1024u && value % 64u == 0u; break;
+        case MBK_OPT_SCAN_STRIP: ok = value <= 1u; break;
         case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;

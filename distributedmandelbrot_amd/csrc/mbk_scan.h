@@ -57,6 +57,16 @@
 // dispatch packet in HOST memory on every trip of a persistent loop unless passed as an argument (pass 1 took
 // 110 us instead of 37), and hipMemset on the null stream does not order against a non-blocking stream.
 //
+// Row strips (round 5, MBK_OPT_SCAN_STRIP; the finish-in-place form only).  The store-only yardstick
+// (profiles/microbench/fill.hip) writes a 4096^2 int32 tile in 15.7 us in the 8x8-block order above and in 10.5 us with 64
+// consecutive elements per wave instruction (uint8: 13.1 / 5.1 us), and the all-exterior tile runs AT the store rate of its
+// pattern.  escape_light_run never looks at the lane number -- a lane is whatever (cr, row, offset) the caller gives it -- so
+// the same loop serves a wave whose 64 lanes are 64 consecutive pixels of ONE row: a "block" is then a 64 x 1 strip, a run is
+// the same 64 columns `stride_by` ROWS apart, every store instruction writes one contiguous 256-byte (int32) / 64-byte
+// (uint8) piece of a row, and a strip the light path cannot finish is finished in place by block_pixel in the same shape
+// (lane = column).  Compact 8x8 blocks exist for the coherence of the lanes' iteration counts; where every pixel is gone
+// within four steps there is nothing to keep coherent.
+//
 // Bit-exactness: a block finished by pass 1 went through the branch-free prologue, which is exact because
 // |z|^2 >= 4 stays >= 4 (the property the grouped test relies on; waves with a pixel near |c| = 2 never use
 // it); every other block is computed by the same code as kernel "group".  Nothing depends on the lists'
@@ -98,6 +108,9 @@ struct ScanArgs {
     uint32_t qtab;          // pass 1: quantised bytes of counts 1..4, packed (byte k-1 = quantise(k))
     uint32_t ranks2;        // pass 2: elements per list covered by the grid (grid = 64 * ranks2)
     uint32_t long_groups;   // pass 2: 1 = dense blocks use 16-step groups (option group_steps == 16)
+    uint32_t strip;         // pass 1, finish-in-place form only: 1 = ROW STRIPS (below); then blocks_x / stride_by / fast_*_end
+                            // of this struct count 64 x 1 strips and rows instead of 8x8 blocks and block rows
+    uint32_t strips_x;      // ... strips per row of the window (the last one may be ragged)
 };
 
 // staged[lane n] = id (id, n wave-uniform): one v_writelane, no memory traffic.
@@ -174,22 +187,28 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
         for (uint32_t k = lane; k < (uint32_t)(sizeof(ScanCursors) / 4u); k += 64u) w[k] = 0u;
     }
     const uint32_t q = blockIdx.x & (kScanQueues - 1u);   // this wave's list
-    uint32_t by = blockIdx.x / p.blocks_x, bx = blockIdx.x - by * p.blocks_x;
-    if (s.xcd_map) {
+    // The wave's region: an 8x8 block, or (row strips, header comment) 64 x 1 pixels; bx / by count regions of that shape.
+    const bool strip = kInline != 0 && s.strip != 0u;
+    const uint32_t bw = strip ? 64u : 8u, bh = strip ? 1u : 8u;
+    const uint32_t regions_x = strip ? s.strips_x : p.blocks_x;
+    uint32_t by = blockIdx.x / regions_x, bx = blockIdx.x - by * regions_x;
+    if (s.xcd_map) {                                     // (never with strips: a strip's store is whole lines or half of one)
         const uint32_t a = bx >> 3, c = bx & 7u;         // bx = 8a + c, c = the XCD this wave runs on
         bx = ((a >> 2) << 5) | (c << 2) | (a & 3u);
     }
-    const uint32_t lx = lane & 7u, ly = lane >> 3;
+    const uint32_t lx = strip ? lane : lane & 7u, ly = strip ? 0u : lane >> 3;
     uint32_t sweeps_here = 0;
     uint32_t staged_d = 0, staged_s = 0, cnt2 = 0;  // staged ids (lane k = k-th id) and their numbers (dense | sparse << 16)
-    const uint32_t nby = (p.nrows + 7u) / 8u;
+    const uint32_t nby = strip ? p.nrows : (p.nrows + 7u) / 8u;
     // per block of a run: the row advances by rowinc, the lane's store offset by einc (bytes of the int32 output
     // when there is one, elements otherwise: escape_light_run)
-    const uint32_t rowinc = s.stride_by * 8u;
+    const uint32_t rowinc = s.stride_by * bh;
     const uint32_t oscale = kCounts ? 4u : 1u;
     const uint32_t einc = rowinc * p.out_pitch * oscale;          // < 2^31 (checked by the host: launch_scan_t)
-    const uint32_t run_cap = (0xffffffffu - (7u * p.out_pitch + 7u) * oscale) / einc;   // offsets stay below 2^32
+    const uint32_t run_cap = (0xffffffffu - ((bh - 1u) * p.out_pitch + bw - 1u) * oscale) / einc;   // offsets stay below 2^32
     while (by < nby) {
+        // (for block_pixel: every 8x8 block the region touches lies inside TileArgs' fast region)
+        const bool interior = strip ? ((bx * 8u + 7u) < p.fast_bx_end && (by >> 3) < p.fast_by_end) : (bx < p.fast_bx_end && by < p.fast_by_end);
         if (bx < s.fast_bx_end && by < s.fast_by_end) {
             // the run of this wave's consecutive light blocks: same column, stride_by block rows apart, up to the end
             // of the regular rows, of the column period, or of what a 32-bit offset spans -- or up to the first block
@@ -199,13 +218,13 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
             uint32_t nrun = (s.fast_by_end - by + s.stride_by - 1u) / s.stride_by;
             if (s.col_period != 0u) nrun = nrun < s.col_period - sweeps_here ? nrun : s.col_period - sweeps_here;
             nrun = nrun < run_cap ? nrun : run_cap;
-            const size_t elem0 = (size_t)(by * 8u + p.out_row0) * p.out_pitch + bx * 8u + p.out_col0;
+            const size_t elem0 = (size_t)(by * bh + p.out_row0) * p.out_pitch + bx * bw + p.out_col0;
             // (the bases are wave-uniform; saying so explicitly keeps them in SGPRs, which the asm needs)
             int32_t *cb = reinterpret_cast<int32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(kCounts ? p.counts + elem0 : nullptr)));
             uint8_t *bb = reinterpret_cast<uint8_t *>(uniform_u64(reinterpret_cast<unsigned long long>(kBytes ? p.bytes + elem0 : nullptr)));
-            const T cr = (T)axis_value(p.re, p.col0 + bx * 8u + lx);   // (a block column inside fast_bx_end: regular samples)
+            const T cr = (T)axis_value(p.re, p.col0 + bx * bw + lx);   // (a block column inside fast_bx_end: regular samples)
             const T a0 = cr * cr;
-            uint32_t row = p.row0 + by * 8u + ly, off = (ly * p.out_pitch + lx) * oscale, n = nrun;
+            uint32_t row = p.row0 + by * bh + ly, off = (ly * p.out_pitch + lx) * oscale, n = nrun;
             int32_t cnt;
             const uint32_t unfinished = escape_light_run<kCounts, kBytes, kStats>(cr, a0, row, rowinc, p.im.step, p.im.start, cnt, cb, bb,
                                                                                   off, einc, s.qtab, n, &acc);
@@ -215,8 +234,7 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
                 // the block at `by`: some lane is still inside after 4 steps (dense: all of them)
                 const bool dense = __ballot(cnt == 5) == ~0ull;
                 if (kInline != 0) {
-                    const int32_t c = block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, s.long_groups != 0u && dense,
-                                                                             bx < p.fast_bx_end && by < p.fast_by_end);
+                    const int32_t c = block_pixel<T, true, 16, kInline == 2>(p, bx * bw, by * bh, lx, ly, s.long_groups != 0u && dense, interior);
                     if (kStats && c >= 0) {
                         heavy_iters += c > 0 ? (uint32_t)c : never_cap;
                         heavy_never += c == 0 ? 1u : 0u;
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(64) void tile_light_kernel(TileArgs p, ScanArgs s)
         } else {
             // not attempted: a ragged edge or the axis' pinned end point
             if (kInline != 0) {
-                const int32_t c = block_pixel<T, true, 16, kInline == 2>(p, bx * 8u, by * 8u, lx, ly, false, bx < p.fast_bx_end && by < p.fast_by_end);
+                const int32_t c = block_pixel<T, true, 16, kInline == 2>(p, bx * bw, by * bh, lx, ly, false, interior);
                 if (kStats && c >= 0) {
                     heavy_iters += c > 0 ? (uint32_t)c : never_cap;
                     heavy_never += c == 0 ? 1u : 0u;

@@ -321,6 +321,11 @@ enum mbk_option {
                               L + 1 runs beside the tile kernel of launch L (MBK_OPT_PREPASS_OVERLAP); a 1024-thread workgroup needs
                               16 free wave slots on ONE CU at once, which a chip full of single-wave workgroups offers only in its
                               drain */
+    MBK_OPT_SCAN_STRIP,    /* scan, finish-in-place form (MBK_OPT_SCAN_INLINE; windows at least 512 pixels wide): a wave's region is 64 x 1
+                              pixels instead of an 8x8 block, so that every store instruction writes one contiguous 256-byte
+                              (int32) / 64-byte (uint8) piece of a row -- the all-exterior tile is bound by its stores, and a
+                              store-only fill of the same box writes rows 1.5x (int32) / 2.5x (uint8) faster than 8x8 blocks
+                              (profiles/r05/fill.txt): 0, [1].  Same loop, same arithmetic: which lane holds which pixel */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

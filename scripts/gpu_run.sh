@@ -19,7 +19,7 @@
 #   pmc          rocprofv3 --pmc passes (cfg2 with the source hash, cfg3)
 #   power        power / clock traces
 #   e2e          level rate, worker end to end
-#   (round 5) fill | gaps:W:OPT+OPT | traceopt:W:OPT+OPT[:args] | extprobe | unitstrace:W,cycle,m_late,h_settled ...
+#   (round 5) strip[:reps] (scripts/strip_ab.py) | fill | gaps:W:OPT+OPT | traceopt:W:OPT+OPT[:args] | extprobe | unitstrace:W,cycle,m_late,h_settled ...
 set -u
 TAG=${1:?tag}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
@@ -143,6 +143,7 @@ PY
       N=gaps_${W}_${O//[=+]/}
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/$N" -o t -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --workload $W --steps 150 --warmup 20 $OPTS > "$OUT/$N.log" 2>&1)
       line "$OUT/$N.log"; python scripts/analyze_gaps.py "$OUT/$N" | tee "$OUT/$N.txt"; rm -rf "$OUT/$N";;
+  strip) timeout 400 python scripts/strip_ab.py ${ARG:-5} 2>&1 | grep -v amdgpu.ids | tee "$OUT/strip_ab.txt";;
   fill) hipcc --offload-arch=gfx950 -O3 -o /tmp/fill profiles/microbench/fill.hip 2> "$OUT/build_fill.log" && timeout 300 /tmp/fill > "$OUT/fill.txt" 2>&1; cat "$OUT/fill.txt"
       b exterior_fillbox --workload exterior --no-cpu-baseline --no-extras; b exterior_both_fillbox --workload exterior --outputs both --no-cpu-baseline --no-extras;;
   skew) [ -x build/units_skew ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o build/units_skew profiles/microbench/units_skew.hip 2> "$OUT/build_units_skew.log"

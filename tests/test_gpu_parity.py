@@ -418,6 +418,7 @@ OPTION_MATRIX = [
     ("group", {"order": 3, "h_settled": 0}), ("group", {"order": 3, "h_settled": 1, "m_late": 0, "xcd_balance": 2, "units_min_light": 0}),
     ("default", {"h_settled": 30}), ("group", {"order": 3, "h_settled": 9, "cycle_detect": 0}),
     ("default", {"prepass_overlap": 2, "classify_wg": 256}), ("group", {"classify_wg": 64, "m_late": 4}),
+    ("scan", {"scan_strip": 0}), ("default", {"scan_strip": 0, "cycle_detect": 0, "scan_waves": 3}),
 ]
 
 
@@ -1020,22 +1021,66 @@ def test_scan_finishes_in_place_what_the_probe_missed(oracle, precision):
     hold hundreds of in-set blocks it does not see (and edge blocks, which never take the light path).  Bit-exact for
     every output set, with and without the cycle test, and identical to the two-pass form."""
     from distributedmandelbrot_amd import MandelbrotDevice
-    for inline, cyc in ((1, 1), (1, 0), (0, 1)):
-        with MandelbrotDevice(0) as dev:
+    for inline, cyc, strip in ((1, 1, 1), (1, 0, 1), (1, 1, 0), (0, 1, 1)):   # (strip: MBK_OPT_SCAN_STRIP, round 5 -- every window
+        with MandelbrotDevice(0) as dev:                                        #  here is wide enough for row strips)
             dev.set_option("scan_inline", inline)
             dev.set_option("cycle_detect", cyc)
+            dev.set_option("scan_strip", strip)
             for view, mrd in NEEDLE_VIEWS:
                 oc, ob, total = _oracle_view_memo(oracle, view, mrd, precision)
                 assert view.width == 1001 or int((oc == 0).sum()) > 300      # the antenna windows do hold part of the set
                 for kernel in ("scan", "default"):
                     c, b, st = dev.compute_view(view, mrd, kernel=kernel, precision=precision)
-                    assert np.array_equal(c, oc), (view, mrd, kernel, precision, inline, cyc, int((c != oc).sum()))
+                    assert np.array_equal(c, oc), (view, mrd, kernel, precision, inline, cyc, strip, int((c != oc).sum()))
                     assert np.array_equal(b, ob) and st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum())
                 # bytes only (what a DataChunk asks for: with the fused statistics no int32 count is written at all) / counts only
                 _, b2, st2 = dev.compute_view(view, mrd, kernel="scan", precision=precision, want_counts=False)
                 c3, _, st3 = dev.compute_view(view, mrd, kernel="scan", precision=precision, want_bytes=False)
                 assert np.array_equal(b2, ob) and np.array_equal(c3, oc)
                 for st in (st2, st3):
-                    assert st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum()), (view, precision, inline, cyc)
+                    assert st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum()), (view, precision, inline, cyc, strip)
+                runs = 1 + int((ob.ravel()[1:] != ob.ravel()[:-1]).sum())
+                assert st2.rle_runs == runs and st2.all_bytes_zero == bool((ob == 0).all()) and st2.all_bytes_one == bool((ob == 1).all())
+
+
+# All-exterior windows (the host probe finds nothing that outlives the light pass -> the finish-in-place form of "scan") in
+# the shapes the row strips must get right: whole DataChunk-sized tiles, widths that are no multiple of 64 (a ragged last
+# strip), a window at an offset inside a larger view, a window that holds the pinned last sample of both axes, the smallest
+# mrd the light path serves (4 steps) and one whose quantiser maps counts 1..4 to different bytes.
+STRIP_VIEWS = [
+    (View(-2.0, -2.0, 1.0, 1.0, 4096, 4096), 1024, None),                      # DataChunk (4,0,0) at the reference's mrd
+    (View(-2.0, -2.0, 4.0, 0.9, 2048, 700), 300, None),                        # counts 1 .. 8+, one pixel of the set (the needle's tip)
+    (View(-2.0, -2.0, 4.0, 0.9, 4120, 300), 6, None),                          # 64 strips + 24 columns; 5 steps: 658 pixels end as 0
+    (View(-2.0, -2.0, 4.0, 0.9, 520, 77), 5, None),                            # the fewest steps the light path serves
+    (View(-2.0, -2.0, 4.0, 4.0, 4096, 4096), 500, (0, 0, 4096, 900)),
+    (View(-2.0, -2.0, 4.0, 4.0, 8192, 8192), 700, (1003, 205, 4997, 1301)),    # odd offsets, odd sizes
+    (View(-2.0, -2.0, 4.0, 4.0, 4100, 4100), 64, (700, 3200, 3400, 900)),      # holds the pinned last sample of both axes
+]
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_scan_row_strips_every_output_set_and_shape(oracle, precision):
+    """MBK_OPT_SCAN_STRIP (round 5): in the finish-in-place form of "scan" a wave's region is 64 x 1 pixels instead of an 8x8
+    block (same asm loop, same arithmetic: which lane holds which pixel), so that a store instruction writes one contiguous
+    piece of a row.  Bit-exact against the oracle for every output set, with the option on and off, with and without the
+    cycle test; the statistics a bytes-only launch sums in the kernel included."""
+    from distributedmandelbrot_amd import MandelbrotDevice
+    expected = [oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd, window=window,
+                            precision=precision) for view, mrd, window in STRIP_VIEWS]
+    for strip, cyc in ((1, 1), (0, 1), (1, 0)):
+        with MandelbrotDevice(0) as dev:
+            dev.set_option("scan_strip", strip)
+            dev.set_option("cycle_detect", cyc)
+            for (view, mrd, window), (oc, ob, total) in zip(STRIP_VIEWS, expected):
+                never = int((oc == 0).sum())
+                for kernel in ("scan", "default"):
+                    c, b, st = dev.compute_view(view, mrd, window=window, kernel=kernel, precision=precision)
+                    assert np.array_equal(c, oc), (view, mrd, window, kernel, precision, strip, cyc, int((c != oc).sum()))
+                    assert np.array_equal(b, ob) and st.pixel_iterations == total and st.never_pixels == never
+                _, b2, st2 = dev.compute_view(view, mrd, window=window, kernel="scan", precision=precision, want_counts=False)
+                c3, _, st3 = dev.compute_view(view, mrd, window=window, kernel="scan", precision=precision, want_bytes=False)
+                assert np.array_equal(b2, ob) and np.array_equal(c3, oc), (view, mrd, window, precision, strip, cyc)
+                for st in (st2, st3):
+                    assert st.pixel_iterations == total and st.never_pixels == never, (view, mrd, window, precision, strip, cyc)
                 runs = 1 + int((ob.ravel()[1:] != ob.ravel()[:-1]).sum())
                 assert st2.rle_runs == runs and st2.all_bytes_zero == bool((ob == 0).all()) and st2.all_bytes_one == bool((ob == 1).all())
