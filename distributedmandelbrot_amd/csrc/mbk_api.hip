@@ -926,6 +926,7 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
     a.perm_mul = 1u;
     a.exact_steps = ctx->opt[MBK_OPT_EXACT_STEPS];
     a.exact_steps_long = std::min(ctx->opt[MBK_OPT_EXACT_STEPS], ctx->opt[MBK_OPT_EXACT_LONG]);
+    a.cyc_window = ctx->opt[MBK_OPT_CYCLE_WINDOW];
     a.order = nullptr;
     a.counts = wc ? d_counts : nullptr;
     a.bytes = wb ? d_bytes : nullptr;
@@ -1097,7 +1098,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
         /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u,
-        /* SCAN_STRIP */ 1u};
+        /* SCAN_STRIP */ 1u, /* CYCLE_WINDOW */ 32u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1621,6 +1622,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_PREPASS_OVERLAP: ok = value <= 2u; break;
         case MBK_OPT_CLASSIFY_WG: ok = value >= 64u && value <= 1024u && value % 64u == 0u; break;
         case MBK_OPT_SCAN_STRIP: ok = value <= 1u; break;
+        case MBK_OPT_CYCLE_WINDOW: ok = value <= 65536u; break;
         case MBK_OPT_EXACT_LONG: ok = value <= 4096u; break;
         case MBK_OPT_SCAN_INLINE: ok = value <= 1u; break;
         case MBK_OPT_WAVE_LIMIT: ok = value <= 7u; break;

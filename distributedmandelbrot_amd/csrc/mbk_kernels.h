@@ -69,6 +69,8 @@ struct TileArgs {
     ReduceSlot *stats;    // may be null; honoured by the finish-in-place light pass only (mbk_scan.h, kStats): the
                           // kernel adds the tile's pixel-iterations and never-escaped count to these partial results
                           // itself, so that a DataChunk needs no int32 counts in HBM at all
+    uint32_t cyc_window;  // cycle test: the reference state's window grows by a quarter while shorter than this many checks,
+                          // doubles from there on (0 = always doubles; mbk_loops.inc, WINDOW SCHEDULE)
 };
 
 // np.linspace sample k (numpy/_core/function_base.py): two roundings, endpoint pinned.
@@ -251,10 +253,10 @@ __device__ __forceinline__ int32_t block_pixel(const TileArgs &p, uint32_t ucol,
             // the set: the blocks a probe or the light pass classified as such); 8 elsewhere
             // (blocks classified as interior skip the per-step prologue when MBK_OPT_EXACT_LONG says so: with the
             // deferred replay a lane that does escape early costs one trip + the block's single fix-up)
-            count = long_groups ? escape_count_group<16, kCycle>(cr, ci, p.mrd, &m, p.exact_steps_long)
-                                : escape_count_group<8, kCycle>(cr, ci, p.mrd, &m, p.exact_steps);
+            count = long_groups ? escape_count_group<16, kCycle>(cr, ci, p.mrd, &m, p.exact_steps_long, p.cyc_window)
+                                : escape_count_group<8, kCycle>(cr, ci, p.mrd, &m, p.exact_steps, p.cyc_window);
         } else {
-            count = escape_count_group<kGroup == 8 ? 8 : 4, kCycle>(cr, ci, p.mrd, &m, p.exact_steps);
+            count = escape_count_group<kGroup == 8 ? 8 : 4, kCycle>(cr, ci, p.mrd, &m, p.exact_steps, p.cyc_window);
         }
     } else {
         count = escape_count_asm<kFmaDouble>(cr, ci, p.mrd, &m);

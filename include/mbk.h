@@ -326,6 +326,13 @@ enum mbk_option {
                               (int32) / 64-byte (uint8) piece of a row -- the all-exterior tile is bound by its stores, and a
                               store-only fill of the same box writes rows 1.5x (int32) / 2.5x (uint8) faster than 8x8 blocks
                               (profiles/r05/fill.txt): 0, [1].  Same loop, same arithmetic: which lane holds which pixel */
+    MBK_OPT_CYCLE_WINDOW,  /* cycle test (MBK_OPT_CYCLE_DETECT): how the window of the saved reference state grows.  A pixel whose
+                              orbit becomes bitwise periodic at step s retires at the first reference state taken after s (plus
+                              lcm(8, period) steps); doubled windows (0: rounds 2-4) take them at steps 8, 16, 32, 64, ... -- 1.44 s
+                              on average.  [32]: the window grows by a quarter (+ 1) while it is shorter than this many 8-step
+                              checks and doubles from there on (long periods -- deep zooms -- need long windows): 6-7 % fewer
+                              wave-steps on full-set views and shallow DataChunks, cfg3 unchanged (scripts/cycle_window_model.c).
+                              0 .. 65536.  Every schedule is exact: a bitwise repeat proves the cycle whichever two steps match */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the

@@ -175,7 +175,15 @@ uint64_t mbo_view_contracted(double start_r, double start_i, double range_r, dou
  * map is a function of those bits, so an exact repeat means the orbit is periodic, every state of the period
  * has already passed the bailout test, and the reference's loop would run to mrd-1 and return 0: the model
  * stops there.  Returns the count; *executed = steps actually run (== the reference's unless it stopped early). */
+int32_t mbo_escape_cycle_w(double cr, double ci, int32_t mrd, int32_t first, int32_t check, uint32_t window_cap, int32_t *executed);
 int32_t mbo_escape_cycle(double cr, double ci, int32_t mrd, int32_t first, int32_t check, int32_t *executed)
+{
+    return mbo_escape_cycle_w(cr, ci, mrd, first, check, 0u, executed);
+}
+
+/* window_cap (round 5, MBK_OPT_CYCLE_WINDOW): the saved state's window grows by a quarter (+ 1) while it is shorter than
+ * window_cap comparisons and doubles from there on; 0 = always doubles (Brent, rounds 2-4).  Any schedule is exact. */
+int32_t mbo_escape_cycle_w(double cr, double ci, int32_t mrd, int32_t first, int32_t check, uint32_t window_cap, int32_t *executed)
 {
     double zr = cr, zi = ci, sr = 0.0, si = 0.0;
     int have = 0;
@@ -207,7 +215,7 @@ int32_t mbo_escape_cycle(double cr, double ci, int32_t mrd, int32_t first, int32
                     *executed = n;
                     return 0;
                 }
-                if (++tc >= win) sr = zr, si = zi, tc = 0, win *= 2u;
+                if (++tc >= win) sr = zr, si = zi, tc = 0, win += win < window_cap ? win / 4u + 1u : win;
             }
         }
     }
@@ -216,8 +224,16 @@ int32_t mbo_escape_cycle(double cr, double ci, int32_t mrd, int32_t first, int32
 }
 
 /* counts and executed steps of a whole view under the model above (row-parallel) */
+void mbo_view_cycle_w(double start_r, double start_i, double range_r, double range_i, uint32_t width, uint32_t height,
+                      int32_t mrd, int32_t first, int32_t check, uint32_t window_cap, int32_t *counts, int32_t *executed, int nthreads);
 void mbo_view_cycle(double start_r, double start_i, double range_r, double range_i, uint32_t width, uint32_t height,
                     int32_t mrd, int32_t first, int32_t check, int32_t *counts, int32_t *executed, int nthreads)
+{
+    mbo_view_cycle_w(start_r, start_i, range_r, range_i, width, height, mrd, first, check, 0u, counts, executed, nthreads);
+}
+
+void mbo_view_cycle_w(double start_r, double start_i, double range_r, double range_i, uint32_t width, uint32_t height,
+                      int32_t mrd, int32_t first, int32_t check, uint32_t window_cap, int32_t *counts, int32_t *executed, int nthreads)
 {
     double *xr = (double *)malloc(sizeof(double) * (width ? width : 1));
     double *xi = (double *)malloc(sizeof(double) * (height ? height : 1));
@@ -231,7 +247,7 @@ void mbo_view_cycle(double start_r, double start_i, double range_r, double range
 #endif
     for (int64_t r = 0; r < (int64_t)height; ++r)
         for (uint32_t c = 0; c < width; ++c)
-            counts[(size_t)r * width + c] = mbo_escape_cycle(xr[c], xi[r], mrd, first, check, &executed[(size_t)r * width + c]);
+            counts[(size_t)r * width + c] = mbo_escape_cycle_w(xr[c], xi[r], mrd, first, check, window_cap, &executed[(size_t)r * width + c]);
     free(xr);
     free(xi);
 }

@@ -65,6 +65,9 @@ class COracle:
         L.mbo_view_cycle.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
         L.mbo_view_cycle.restype = None
+        L.mbo_view_cycle_w.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+        L.mbo_view_cycle_w.restype = None
         L.mbo_max_threads.restype = C.c_int
         L.mbo_have_avx512.restype = C.c_int
         L.mbo_view_avx512.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32,
@@ -121,13 +124,14 @@ class COracle:
         self.lib.mbo_view_contracted(start_r, start_i, range_r, range_i, width, height, mrd, counts.ctypes.data, nthreads)
         return counts
 
-    def view_cycle(self, start_r, start_i, range_r, range_i, width, height, mrd, *, first=8, check=16, nthreads=0):
+    def view_cycle(self, start_r, start_i, range_r, range_i, width, height, mrd, *, first=8, check=16, window_cap=0, nthreads=0):
         """Model of the GPU kernels' cycle test (see mbo_escape_cycle): (counts, executed steps per pixel).  A what-if
-        for tests of the claim and for scripts/cycle_model.py, not the oracle."""
+        for tests of the claim and for scripts/cycle_model.py, not the oracle.  window_cap: the schedule of
+        MBK_OPT_CYCLE_WINDOW (0 = the window of the saved state always doubles, rounds 2-4; the library's default is 32)."""
         counts = np.empty((height, width), np.int32)
         executed = np.empty((height, width), np.int32)
-        self.lib.mbo_view_cycle(start_r, start_i, range_r, range_i, width, height, mrd, first, check,
-                                counts.ctypes.data, executed.ctypes.data, nthreads)
+        self.lib.mbo_view_cycle_w(start_r, start_i, range_r, range_i, width, height, mrd, first, check, window_cap,
+                                  counts.ctypes.data, executed.ctypes.data, nthreads)
         return counts, executed
 
     def have_avx512(self) -> bool:

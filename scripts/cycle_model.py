@@ -28,6 +28,7 @@ ap.add_argument("--view", type=float, nargs=4, default=[-2.0, -1.5, 3.0, 3.0])
 ap.add_argument("--fixed", type=float, default=40.0, help="VALU instructions per block outside the loops (calibrated on PMC)")
 ap.add_argument("--replay", default="deferred", choices=["deferred", "spot"])
 ap.add_argument("--check", type=int, default=8, help="steps between two bitwise state compares of the cycle test")
+ap.add_argument("--window-cap", type=int, default=32, help="MBK_OPT_CYCLE_WINDOW: the saved state's window grows by a quarter below this many checks, doubles from there on (0 = always doubles, rounds 2-4)")
 args = ap.parse_args()
 o = COracle()
 N, T, E = args.size, args.mrd - 1, 8
@@ -110,7 +111,7 @@ print(f"  all-in-set blocks {int(inset.sum())}: {strict[inset].sum()/1e6:.1f} M;
       f"{strict[mid].sum()/1e6:.1f} M (lock-step floor {last[mid].sum()*6.125/1e6:.1f} M); blocks done within {E} steps "
       f"{int((last <= E).sum())}: {strict[last <= E].sum()/1e6:.1f} M")
 
-cc, ex = o.view_cycle(sr, si, rr, ri, N, N, args.mrd, first=E, check=args.check)
+cc, ex = o.view_cycle(sr, si, rr, ri, N, N, args.mrd, first=E, check=args.check, window_cap=args.window_cap)
 assert np.array_equal(cc, c)
 never = c == 0
 print(f"cycle test: {100*(ex[never] < T).mean():.1f} % of the {int(never.sum())} never-escaping pixels retire early "

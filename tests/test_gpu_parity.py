@@ -419,6 +419,8 @@ OPTION_MATRIX = [
     ("default", {"h_settled": 30}), ("group", {"order": 3, "h_settled": 9, "cycle_detect": 0}),
     ("default", {"prepass_overlap": 2, "classify_wg": 256}), ("group", {"classify_wg": 64, "m_late": 4}),
     ("scan", {"scan_strip": 0}), ("default", {"scan_strip": 0, "cycle_detect": 0, "scan_waves": 3}),
+    ("group", {"cycle_window": 0}), ("default", {"cycle_window": 5}), ("scan", {"cycle_window": 65536, "group_steps": 8}),
+    ("default", {"cycle_window": 1, "h_settled": 0, "m_late": 0}),
 ]
 
 
@@ -728,7 +730,7 @@ def test_cycle_detection_is_bit_exact(oracle, kernel, precision):
     the strict loop (WorkerCUDA.py:39-68 runs such a pixel to mrd-1 and returns 0) on views made of set interior,
     for both settings, for every group size with a cycle test, and for mrd values around the loops' trip limits."""
     from distributedmandelbrot_amd import MandelbrotDevice
-    for cyc, opts in ((1, {}), (1, {"group_steps": 8}), (0, {})):
+    for cyc, opts in ((1, {}), (1, {"group_steps": 8}), (0, {}), (1, {"cycle_window": 0}), (1, {"cycle_window": 65536, "group_steps": 8})):
         with MandelbrotDevice(0) as dev:
             dev.set_option("cycle_detect", cyc)
             for k, v in opts.items():

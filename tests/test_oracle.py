@@ -218,9 +218,10 @@ def test_cycle_retirement_claim(oracle):
     saved = 0
     for sr, si, rr, ri, w, h, mrd in cases:
         strict, _, _ = oracle.view(sr, si, rr, ri, w, h, mrd, want_bytes=False)
-        for first, check in ((8, 8), (8, 16), (0, 1), (8, 32), (3, 7)):   # (8, 8) = the kernels' schedule
-            counts, executed = oracle.view_cycle(sr, si, rr, ri, w, h, mrd, first=first, check=check)
-            assert np.array_equal(counts, strict), (sr, si, mrd, first, check)
+        # (8, 8, 32) = the kernels' schedule (MBK_OPT_CYCLE_WINDOW = 32, round 5; 0 = the doubled windows of rounds 2-4)
+        for first, check, wcap in ((8, 8, 32), (8, 8, 0), (8, 16, 0), (0, 1, 0), (8, 32, 5), (3, 7, 65536), (0, 8, 1)):
+            counts, executed = oracle.view_cycle(sr, si, rr, ri, w, h, mrd, first=first, check=check, window_cap=wcap)
+            assert np.array_equal(counts, strict), (sr, si, mrd, first, check, wcap)
             ref_steps = np.where(strict > 0, strict, mrd - 1)
             assert (executed <= ref_steps).all() and (executed[strict > 0] == strict[strict > 0]).all()
             saved += int((ref_steps - executed).sum())
