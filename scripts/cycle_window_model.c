@@ -92,6 +92,36 @@ static int32_t run_alt(double cr, double ci, int32_t mrd, int32_t first, int shi
     return mrd > 1 ? mrd - 1 : 0;
 }
 
+/* Both at every check (priced, not built): compare with the state of 8 steps ago AND with the saved one -- periods 1, 2, 4, 8
+ * retire at the first check after the orbit has settled, the rest under the product's schedule (a quarter's growth below `wcap`
+ * checks, doubling above).  Costs two more 64-bit compares and two moves per 8 steps (+1.5-2 % instructions). */
+static int32_t run_both(double cr, double ci, int32_t mrd, int32_t first, uint32_t wcap, int with_prev, int32_t *cnt)
+{
+    double zr = cr, zi = ci, sr = 0, si = 0, pr = 0, pi = 0;
+    int have = 0;
+    uint32_t tc = 0, win = 1;
+    for (int32_t n = 1; n < mrd; ++n) {
+        const double a = zr * zr, b = zi * zi, t = a - b, w = 2.0 * zr, u = w * zi;
+        zr = t + cr;
+        zi = u + ci;
+        if (zr * zr + zi * zi >= 4.0) { *cnt = n; return n; }
+        if (n >= first && (n - first) % 8 == 0) {
+            if (!have) { sr = zr; si = zi; have = 1; }
+            else {
+                if (with_prev && memcmp(&zr, &pr, 8) == 0 && memcmp(&zi, &pi, 8) == 0) { *cnt = 0; return n; }
+                if (memcmp(&zr, &sr, 8) == 0 && memcmp(&zi, &si, 8) == 0) { *cnt = 0; return n; }
+                if (++tc >= win) {
+                    sr = zr; si = zi; tc = 0;
+                    win += win < wcap ? (win >> 2) + 1u : win;   /* the product's MBK_G_CYC_OOL */
+                }
+            }
+            pr = zr; pi = zi;
+        }
+    }
+    *cnt = 0;
+    return mrd > 1 ? mrd - 1 : 0;
+}
+
 /* floor: the first check step (n >= first, (n - first) % 8 == 0) at or after BOTH the orbit's entry into its bitwise cycle and
  * one full lcm(8, period) later (a match needs two states lcm apart) -- what an oracle that knew the period could do */
 static int32_t run_floor(double cr, double ci, int32_t mrd, int32_t first, double *hr, double *hi)
@@ -133,7 +163,7 @@ int main(int argc, char **argv)
         {"DataChunk (4,1,1) mrd 1024", -1.0, -1.0, 1.0, 1.0, 4096, 1024},
     };
     const int nviews = argc > 1 ? atoi(argv[1]) : 4;
-    const int shifts[] = {0, 1, 2, 3, -1, 100, 101, 102};   /* 100 + s: the alternating scheme with shift s */
+    const int shifts[] = {0, 1, 2, 3, -1, 100, 101, 102, 200, 201};   /* 100 + s: the alternating scheme with shift s; 200 / 201: the product's schedule (cap 32) without / with the state of 8 steps ago */
     for (int v = 0; v < nviews && v < 4; ++v) {
         const uint32_t N = views[v].n;
         const int32_t mrd = views[v].mrd;
@@ -142,7 +172,7 @@ int main(int argc, char **argv)
         axis(views[v].si, views[v].ri, N, xi);
         const uint32_t nb = N / 8;
         printf("== %s\n", views[v].name);
-        for (int pol = -1; pol < 8; ++pol) {
+        for (int pol = -1; pol < 10; ++pol) {
             double px_steps = 0, wave_steps = 0;
             long long never = 0, early = 0;
 #pragma omp parallel for schedule(dynamic, 2) reduction(+ : px_steps, wave_steps, never, early)
@@ -159,7 +189,8 @@ int main(int argc, char **argv)
                             if (pol < 0) {
                                 ex = run_floor(xr[bx * 8 + lx], xi[by * 8 + ly], mrd, 8, hr, hi);
                             } else {
-                                ex = shifts[pol] >= 100 ? run_alt(xr[bx * 8 + lx], xi[by * 8 + ly], mrd, 8, shifts[pol] - 100, &cnt)
+                                ex = shifts[pol] >= 200 ? run_both(xr[bx * 8 + lx], xi[by * 8 + ly], mrd, 8, 32u, shifts[pol] - 200, &cnt)
+                                   : shifts[pol] >= 100 ? run_alt(xr[bx * 8 + lx], xi[by * 8 + ly], mrd, 8, shifts[pol] - 100, &cnt)
                                                         : run(xr[bx * 8 + lx], xi[by * 8 + ly], mrd, 8, shifts[pol], &cnt);
                                 if (cnt == 0) { ++never; if (ex < mrd - 1) ++early; }
                             }
@@ -173,9 +204,13 @@ int main(int argc, char **argv)
             if (pol < 0)
                 printf("  floor (period known)          pixel-steps %8.1f M  wave-steps %7.3f M  lane activity %.3f\n", px_steps / 1e6, wave_steps / 1e6,
                        px_steps / 64.0 / wave_steps);
+            else if (shifts[pol] >= 200)
+                printf("  product's schedule (cap 32)%s  pixel-steps %8.1f M  wave-steps %7.3f M  lane activity %.3f   never %lld, retired early %.1f %%\n",
+                       shifts[pol] == 201 ? " + state of 8 steps ago" : "                       ", px_steps / 1e6, wave_steps / 1e6, px_steps / 64.0 / wave_steps, never,
+                       never ? 100.0 * early / never : 0.0);
             else
                 printf("  %s win += max(1, win >> %2d)%s  pixel-steps %8.1f M  wave-steps %7.3f M  lane activity %.3f   never %lld, retired early %.1f %%\n",
-                       shifts[pol] >= 100 ? "alternating," : "            ", shifts[pol] % 100 > 50 ? -1 : shifts[pol] % 100, shifts[pol] == 0 ? " (now)" : "      ", px_steps / 1e6, wave_steps / 1e6, px_steps / 64.0 / wave_steps, never,
+                       shifts[pol] >= 100 ? "alternating," : "            ", shifts[pol] % 100 > 50 ? -1 : shifts[pol] % 100, shifts[pol] == 0 ? " (r2-4)" : "       ", px_steps / 1e6, wave_steps / 1e6, px_steps / 64.0 / wave_steps, never,
                        never ? 100.0 * early / never : 0.0);
             fflush(stdout);
         }
