@@ -73,6 +73,7 @@ int main(int argc, char **argv)
     const bool cyc = argc > 3 && atoi(argv[3]) != 0;          // the library's default: the cycle test
     const int m_late = argc > 4 ? atoi(argv[4]) : 0;          // MBK_OPT_M_LATE
     const int h_settled = argc > 5 ? atoi(argv[5]) : 0;       // MBK_OPT_H_SETTLED (k: threshold 10^-k)
+    const uint32_t cyc_window = argc > 6 ? (uint32_t)atoi(argv[6]) : 32u;   // MBK_OPT_CYCLE_WINDOW (the library's default)
     const double settle_thr = h_settled ? pow(10.0, -(double)h_settled) : 0.0;
     const uint32_t W = 4096, H = 4096, mrd = 1000;
     mbk::TileArgs a; memset(&a, 0, sizeof(a));
@@ -82,7 +83,7 @@ int main(int argc, char **argv)
     if (wl == "chunk_l1") { a.re = mk(-2.0, 4.0, W); a.im = mk(-2.0, 4.0, H); }
     else { a.re = mk(-2.0, 3.0, W); a.im = mk(-1.5, 3.0, H); }
     a.ncols = W; a.nrows = H; a.out_pitch = W; a.mrd = mrd; a.quant_rcp = 1.0 / mrd;
-    a.exact_steps = 8; a.exact_steps_long = 0; a.ring_possible = 1;
+    a.exact_steps = 8; a.exact_steps_long = 0; a.ring_possible = 1; a.cyc_window = cyc_window;
     a.blocks_x = W / 8;
     a.fast_bx_end = W / 8 - 1; a.fast_by_end = H / 8 - 1;   // (conservative: the blocks holding an axis' last sample take the general path)
     a.perm_mul = 1;
@@ -109,7 +110,7 @@ int main(int argc, char **argv)
         CHECK(hipEventRecord(e1));
         CHECK(hipDeviceSynchronize());
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep >= 156) printf("%s rep %d (cycle test %d, m_late %d, h_settled %d): late M %u, H %u, settled H %u, V units %u, M %u -> %u workgroups, %.3f ms\n", wl.c_str(), rep, (int)cyc, m_late, h_settled, n_ml, cnt[0], n_hs, cnt[1], cnt[2], total, ms);
+        if (rep >= 156) printf("%s rep %d (cycle test %d, m_late %d, h_settled %d, cycle window %u): late M %u, H %u, settled H %u, V units %u, M %u -> %u workgroups, %.3f ms\n", wl.c_str(), rep, (int)cyc, m_late, h_settled, cyc_window, n_ml, cnt[0], n_hs, cnt[1], cnt[2], total, ms);
     }
     const uint32_t total = cnt[0] + cnt[1] + cnt[2] + n_ml + n_hs;
     std::vector<Rec> h(total);

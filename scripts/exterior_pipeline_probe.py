@@ -4,8 +4,8 @@ with k tiles in flight; prints the rate and the host time of submit / wait.  Run
     rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --stats
 to see the HIP calls and the GPU side (scripts/gpu_run.sh section `extprobe`).
     python scripts/exterior_pipeline_probe.py [tiles] [slots] [lazy 0|1]"""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # (run from /tmp under rocprofv3)
 import numpy as np
 from distributedmandelbrot_amd import MandelbrotDevice
 

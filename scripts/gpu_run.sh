@@ -4,7 +4,7 @@
 # Everything lands in gpurun_out/TAG/.  Sections (run in the order given):
 #   smoke        __graft_entry__.smoke()
 #   tests        the whole `pytest -m gpu` suite            tests:EXPR  only tests matching -k EXPR
-#   soak[:S]     randomized parity soak for S seconds (default 120)
+#   soak[:S[:SEED]]  randomized parity soak for S seconds (default 120; seed 17)
 #   issue        profiles/microbench/valu_issue.hip (fp64 issue rate in shader cycles)
 #   clock[:W:K ...]  the shader clock (s_memtime / s_memrealtime, a one-wave probe in a second process) while bench.py runs workload W for K steps
 #   headline     bench.py as the driver runs it
@@ -34,7 +34,8 @@ for SEC in "$@"; do
   smoke) timeout 600 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?"; tail -1 "$OUT/smoke.log";;
   tests) if [ -n "$ARG" ]; then timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider -k "$ARG" > "$OUT/pytest_gpu_subset.txt" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest_gpu_subset.txt"; grep -E "^FAILED|^ERROR" "$OUT/pytest_gpu_subset.txt" | cut -c1-300 | head -10
          else timeout 2400 python -m pytest tests -m gpu -q --maxfail=8 -p no:cacheprovider > "$OUT/pytest_gpu.txt" 2>&1; echo "pytest rc=$?"; tail -3 "$OUT/pytest_gpu.txt"; grep -E "^FAILED|^ERROR" "$OUT/pytest_gpu.txt" | cut -c1-300 | head -10; fi;;
-  soak) timeout 900 python scripts/gpu_soak.py ${ARG:-120} 17 > "$OUT/soak.txt" 2>&1; tail -2 "$OUT/soak.txt";;
+  soak) S=${ARG%%:*}; SEED=${ARG#*:}; [ "$SEED" = "$ARG" ] && SEED=17   # soak[:seconds[:seed]]
+        timeout 900 python scripts/gpu_soak.py ${S:-120} $SEED > "$OUT/soak.txt" 2>&1; tail -2 "$OUT/soak.txt";;
   issue) hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue profiles/microbench/valu_issue.hip 2> "$OUT/build_issue.log" && timeout 300 /tmp/valu_issue > "$OUT/valu_issue.txt" 2>&1; cut -c1-200 "$OUT/valu_issue.txt";;
   clock) hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue profiles/microbench/valu_issue.hip 2> "$OUT/build_issue.log"
       for spec in ${ARG:-cfg2:4000 inset:700 cfg3:160 chunk_l1:6000}; do W=${spec%%:*}; K=${spec#*:}
@@ -105,9 +106,9 @@ PY
         done; done
       rm -rf "$OUT"/pmc_*_?;;
   unitstrace) hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/units_trace profiles/microbench/units_trace.hip 2> "$OUT/build_units_trace.log"
-      for A in ${ARG:-cfg2,0,0,0 chunk_l1,0,0,0}; do   # workload,cycle test,m_late,h_settled
+      for A in ${ARG:-cfg2,0,0,0 chunk_l1,0,0,0}; do   # workload,cycle test,m_late,h_settled[,cycle window (default 32)]
         set -- ${A//,/ }; W=$1; N=units_trace_${A//,/_}
-        timeout 300 /tmp/units_trace $W "$OUT/$N.bin" ${2:-0} ${3:-0} ${4:-0} > "$OUT/$N.txt" 2>&1
+        timeout 300 /tmp/units_trace $W "$OUT/$N.bin" ${2:-0} ${3:-0} ${4:-0} ${5:-32} > "$OUT/$N.txt" 2>&1
         timeout 600 python scripts/analyze_units_trace.py "$OUT/$N.bin" >> "$OUT/$N.txt" 2>&1
         grep -v "^  *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]* *[0-9.]*$" "$OUT/$N.txt" | tail -48; rm -f "$OUT/$N.bin"
       done;;
