@@ -353,6 +353,42 @@ def test_cfg4_full_width_bands_f32(gpu, oracle, kernel):
         assert np.array_equal(b, ob) and st.pixel_iterations == total, (kernel, row0)
 
 
+def test_cfg4_full_image_two_independent_loops_agree_f32(gpu):
+    """BASELINE cfg4 at its FULL size (16384^2, mrd 50000, fp32): the CPU oracle would need hours for the whole image, so
+    the whole-image check is a size-independent one.  The library's default path (grouped bailout with the deferred replay,
+    heavy-first dispatch list, cycle test on: iterations skipped) and kernel "asm" with the cycle test off (one exact test per
+    step, an escaped lane leaves EXEC, every iteration executed, image order) are two separately written loops; they must
+    agree on all 268 435 456 counts, and the 1 024-row band of the image that the strict-binary32 oracle DID compute
+    (tests/golden/bench_outputs.json "cfg4_band": 115 s on the CPU) must hash to the oracle's sha256 inside it."""
+    import hashlib
+    import json
+    import os
+    import torch
+    from distributedmandelbrot_amd import MandelbrotDevice
+    view, mrd = CFG4
+    n = view.width * view.height
+    s = torch.cuda.current_stream().cuda_stream
+    a = torch.full((n,), -7, dtype=torch.int32, device="cuda:0")
+    gpu.launch_view(view, mrd, d_counts=a.data_ptr(), stream=s, precision="f32")
+    st_a = gpu.reduce_counts(a.data_ptr(), n, mrd, stream=s)
+    b = torch.full((n,), -9, dtype=torch.int32, device="cuda:0")
+    with MandelbrotDevice(0) as strict:
+        strict.set_option("cycle_detect", 0)
+        strict.launch_view(view, mrd, d_counts=b.data_ptr(), stream=s, precision="f32", kernel="asm")
+        st_b = strict.reduce_counts(b.data_ptr(), n, mrd, stream=s)
+        torch.cuda.synchronize()
+    assert torch.equal(a, b), int((a != b).sum())
+    assert st_a.pixel_iterations == st_b.pixel_iterations and st_a.never_pixels == st_b.never_pixels
+    assert int(a.min()) >= 0 and int(a.max()) <= mrd - 1
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bench_outputs.json")))["cfg4_band"]
+    assert g["view"] == [view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height] and g["mrd"] == mrd
+    _, row0, ncols, nrows = g["window"]
+    band = a.view(view.height, view.width)[row0:row0 + nrows].contiguous().cpu().numpy()
+    assert ncols == view.width and hashlib.sha256(band.tobytes()).hexdigest() == g["counts_sha256"]
+    assert int(np.where(band > 0, band, mrd - 1).astype(np.int64).sum()) == g["pixel_iterations"]
+    assert int((band == 0).sum()) == g["never_pixels"]
+
+
 def test_full_size_cfg5_smooth(gpu, oracle):
     """BASELINE cfg5 (4096^2, mrd 5000, continuous colouring) at its named size: counts bit-exact, the
     continuous value within 1e-12 * mrd of the libm evaluation on the same |z_n|^2."""
