@@ -33,6 +33,7 @@ MBK_PRECISION_F32 = 0x1000
 MBK_LAZY_UNIFORM = 0x2000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}
 MBK_SLOTS = 4
+MBK_WORKER_DEPTH = 3
 MBK_INFO_SCAN_WG_PER_CU = 100
 MBK_INFO_XCD_SHARE = 110
 MBK_CODEC_RAW = 0x00

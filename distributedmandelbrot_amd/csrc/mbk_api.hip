@@ -48,10 +48,13 @@ struct StreamScratch {
     // kernels of the launches before it still read the others
     uint32_t *d_order[kOrderRing] = {};
     uint32_t *d_ctl = nullptr;    // 8 words per list: the units pre-pass' counters (H, V, M | late M, settled H, ticket), zero between launches
+    bool ctl_dirty = true;        // the counters must be cleared (on the pre-pass' own stream) before the next pre-pass: never used
+                                  // yet, or a launch failed after its pre-pass was enqueued and may have left a ticket behind
     size_t order_cap = 0;         // regions
     unsigned order_turn = 0;
     hipStream_t aux = nullptr;    // the pre-pass stream
     uint32_t aux_prio = 0;        // 1 default priority, 2 highest (MBK_OPT_PREPASS_OVERLAP = 2)
+    int pp_last = -1;             // MBK_OPT_PREPASS_OVERLAP of the last ordered launch on this stream (a change drains both streams)
     hipEvent_t ev_cls[kOrderRing] = {};   // pre-pass into list k finished
     hipEvent_t ev_done[kOrderRing] = {};  // the tile kernel that read list k finished
     bool done_valid[kOrderRing] = {};
@@ -109,6 +112,11 @@ struct mbk_ctx {
     int scan_occ_inline[2] = {0, 0};        // the same for pass 1 in its finish-in-place form (MBK_OPT_SCAN_INLINE)
     uint32_t wave_limit_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MBK_OPT_WAVE_LIMIT: dynamic LDS bytes per single-wave workgroup
                                             // that leave room for 4 x k workgroups per CU (k = index; 0 = no padding)
+    // the host probe of the last window (window_heavy_share): one submit asks for it up to three times -- the copy decision of
+    // MBK_LAZY_UNIFORM, the kernel choice, the units rule -- and all three must rest on the same evaluation
+    struct ProbeKey { Axis re, im; uint32_t col0, row0, ncols, nrows; } probe_key = {};
+    double probe_share = 0.0;
+    bool probe_valid = false;
     hipDeviceProp_t prop;
     std::string err;
 };
@@ -315,6 +323,7 @@ static int get_scratch(mbk_ctx *ctx, hipStream_t stream, StreamScratch **out)
 static void set_window_facts(TileArgs &a, bool f32);
 static void shares_from_fractions(const double *f, uint32_t *cum);
 static double window_heavy_share(const TileArgs &a);
+static double window_heavy_share(mbk_ctx *ctx, const TileArgs &a);
 
 // Kernel "units": new H fractions for the eight XCDs from the time stamps of the launches on this stream that have finished
 // since the last look (mbk_units.h).  A launch that dealt XCD x the fraction f_x of the H list and saw it deal its last
@@ -390,7 +399,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     a.perm_mul = order_mode == 1 ? coprime_multiplier(grid.x) : 1u;
     a.order = nullptr;
     int order_slot = -1;
-    bool mid_first = false;
+    bool mid_first = false, order_overlap = false;
     StreamScratch *order_sc = nullptr;
     // order 3 = "units" (mbk_units.h): the light blocks of eight neighbouring block columns are ONE workgroup.  Where the
     // units kernel cannot serve a launch (outputs, widths, step counts it has no form for) the launch takes order 2.
@@ -403,7 +412,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     // -0.3 % / cycle test +4.7 %, DataChunk (1,0,0) (0.8) +2.1 % / +9.7 %, cfg3 (none) -0.7 % / 0.
     double unit_share = 0.0;
     if (units) {
-        unit_share = window_heavy_share(a);
+        unit_share = window_heavy_share(ctx, a);
         units = (1.0 - unit_share) * 65536.0 >= (double)ctx->opt[MBK_OPT_UNITS_MIN_LIGHT];
     }
     if (order_mode >= 2 && grid.x >= 16384u && (uint32_t)a.mrd > 2u * probe_steps && a.blocks_x <= 0xffffu && by <= 0xffffu) {
@@ -413,12 +422,28 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         StreamScratch *sc = nullptr;
         int rc = get_scratch(ctx, stream, &sc);
         if (rc != MBK_OK) return rc;
-        const bool overlap = ctx->opt[MBK_OPT_PREPASS_OVERLAP] != 0u;
+        // MBK_OPT_PREPASS_OVERLAP: 0 the pre-pass runs on the caller's stream, in order (one queue, no event: +4..5 us per cfg2
+        // launch back to back, profiles/r06/prepass_modes_ab.txt); 1 / 2 on an auxiliary stream (2: at the highest priority), tied
+        // to the tile kernel by events.  (Round 6 also tried it as an ANY-ORDER launch on the caller's stream -- an AQL packet
+        // without the barrier bit, hipExtAnyOrderLaunch, which would start in the previous tile kernel's drain -- but gfx950
+        // ignores the flag: profiles/microbench/anyorder.hip, profiles/r06/anyorder.txt.)
+        const uint32_t pp_mode = ctx->opt[MBK_OPT_PREPASS_OVERLAP];
+        const bool overlap = pp_mode != 0u;
         // MBK_OPT_PREPASS_OVERLAP = 2: the auxiliary stream has the highest priority, so that the pre-pass of launch L + 1 gets
         // its workgroups in while the tile kernel of launch L is in full swing instead of waiting for its drain (round 5: once
         // the launch no longer ends in a 20 us drain, a pre-pass that waited for it sits on the critical path)
-        const uint32_t want_prio = ctx->opt[MBK_OPT_PREPASS_OVERLAP] == 2u ? 2u : 1u;
-        if (sc->aux && sc->aux_prio != want_prio) {
+        const uint32_t want_prio = pp_mode == 2u ? 2u : 1u;
+        if (sc->pp_last != (int)pp_mode) {
+            // the lists' hand-over differs by mode (events between two streams / the order of one queue): nothing of the old
+            // mode may be in flight when the first launch of the new one picks its list
+            if (sc->pp_last >= 0) {
+                MBK_HIP(ctx, hipStreamSynchronize(stream));
+                if (sc->aux) MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
+            }
+            for (int k = 0; k < kOrderRing; ++k) sc->done_valid[k] = false;
+            sc->pp_last = (int)pp_mode;
+        }
+        if (overlap && sc->aux && sc->aux_prio != want_prio) {
             MBK_HIP(ctx, hipStreamSynchronize(stream));
             MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
             (void)hipStreamDestroy(sc->aux);
@@ -430,7 +455,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                 sc->done_valid[k] = false;
             }
         }
-        if (!sc->aux) {
+        if (overlap && !sc->aux) {
             if (want_prio == 2u) {
                 int least = 0, greatest = 0;
                 MBK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -446,7 +471,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         if (grid.x > sc->order_cap) {
             // the old lists may still be read / written by kernels in flight on the two streams
             MBK_HIP(ctx, hipStreamSynchronize(stream));
-            MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
+            if (sc->aux) MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
             for (int k = 0; k < kOrderRing; ++k) {
                 if (sc->d_order[k]) (void)hipFree(sc->d_order[k]);
                 sc->d_order[k] = nullptr;
@@ -462,14 +487,14 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         // Pre-pass of THIS launch on the aux stream: it depends on the window only, not on anything the caller's
         // stream computes, so it may run while the previous launch's tile kernel is still busy (memset + classify
         // are 13 us of a 577 us cfg2 step, with the chip nearly idle).  List k is free once the tile kernel that
-        // read it two launches ago has finished (ev_done); the tile kernel waits for its list (ev_cls).  With
+        // read it kOrderRing launches ago has finished (ev_done); the tile kernel waits for its list (ev_cls).  With
         // prepass_overlap = 0 everything goes to the caller's stream, as in rounds 1-2.
         const unsigned k = sc->order_turn++ % (unsigned)kOrderRing;
         uint32_t *ord = sc->d_order[k];
         uint32_t *cursors = ord + grid.x;   // right behind the list: the tile kernel finds them at order[gridDim.x]
         hipStream_t pre = overlap ? sc->aux : stream;
         if (overlap && sc->done_valid[k]) MBK_HIP(ctx, hipStreamWaitEvent(sc->aux, sc->ev_done[k], 0));
-        // (serial mode needs no wait: the list's last reader, two launches ago, ran on this same stream)
+        // (serial mode needs no wait: the list's last reader, kOrderRing launches ago, ran on this same stream)
         if (units) {
             // MBK_OPT_M_LATE = s > 0: M blocks whose centre pixel escapes at step >= s open the dispatch order; MBK_OPT_H_SETTLED
             // = k > 0 (with the cycle test only): H blocks whose probe orbit is within 10^-k of settled close the front list
@@ -479,7 +504,17 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             // here and put back to zero by the pre-pass itself (mbk_units.h: classify_units_kernel)
             if (!sc->d_ctl) {
                 MBK_HIP(ctx, hipMalloc((void **)&sc->d_ctl, (size_t)kOrderRing * 8u * sizeof(uint32_t)));
-                MBK_HIP(ctx, hipMemset(sc->d_ctl, 0, (size_t)kOrderRing * 8u * sizeof(uint32_t)));
+                sc->ctl_dirty = true;
+            }
+            if (sc->ctl_dirty) {
+                // ON the stream the pre-pass runs on (a hipMemset on the null stream does not order against a
+                // non-blocking stream -- what commit d786d61 removed for the scan cursors), and behind whatever pre-pass may
+                // still be running there and on the caller's stream; also after a failed launch (a pre-pass that did not run
+                // to its last workgroup leaves its ticket behind, and no later one would ever clear it)
+                if (sc->aux) MBK_HIP(ctx, hipStreamSynchronize(sc->aux));
+                MBK_HIP(ctx, hipStreamSynchronize(stream));
+                MBK_HIP(ctx, hipMemsetAsync(sc->d_ctl, 0, (size_t)kOrderRing * 8u * sizeof(uint32_t), pre));
+                sc->ctl_dirty = false;
             }
             uint32_t *ctl = sc->d_ctl + 8u * k;
             // the shares of the eight XCDs: MBK_OPT_XCD_BALANCE 0 even, 1 following the stamps of earlier launches on this
@@ -530,6 +565,7 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
             MBK_HIP(ctx, hipStreamWaitEvent(stream, sc->ev_cls[k], 0));
         }
         order_slot = (int)k;
+        order_overlap = overlap;
         order_sc = sc;
         a.order = ord;
         a.ngrid = grid.x;
@@ -599,8 +635,14 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 8>), grid, block, lds, stream, a);
     else
         hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 4>), grid, block, lds, stream, a);
-    MBK_HIP(ctx, hipGetLastError());
-    if (order_slot >= 0) {   // list `order_slot` is busy until this tile kernel has finished
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            if (order_sc) order_sc->ctl_dirty = true;   // a pre-pass may be stuck half-way: clear its counters before the next one
+            return fail(ctx, MBK_ERR_HIP, std::string("tile launch: ") + hipGetErrorString(e));
+        }
+    }
+    if (order_slot >= 0 && order_overlap) {   // list `order_slot` is busy until this tile kernel has finished
         MBK_HIP(ctx, hipEventRecord(order_sc->ev_done[order_slot], stream));
         order_sc->done_valid[order_slot] = true;
     }
@@ -727,6 +769,24 @@ static double window_heavy_share(const TileArgs &a)
     return (double)inside / (double)(k * k);
 }
 
+// ... evaluated once per window: the last window's answer is kept on the ctx
+static double window_heavy_share(mbk_ctx *ctx, const TileArgs &a)
+{
+    mbk_ctx::ProbeKey k;
+    std::memset(&k, 0, sizeof(k));
+    k.re = a.re;
+    k.im = a.im;
+    k.col0 = a.col0;
+    k.row0 = a.row0;
+    k.ncols = a.ncols;
+    k.nrows = a.nrows;
+    if (ctx->probe_valid && std::memcmp(&k, &ctx->probe_key, sizeof(k)) == 0) return ctx->probe_share;
+    ctx->probe_key = k;
+    ctx->probe_share = window_heavy_share(a);
+    ctx->probe_valid = true;
+    return ctx->probe_share;
+}
+
 // Kernel "scan": a persistent light pass over every 8x8 block, then one workgroup per block it listed as
 // unfinished (mbk_scan.h).  Launches the light pass cannot serve go to launch_blocks ("group").
 template <typename T>
@@ -776,7 +836,9 @@ static int launch_scan_t(mbk_ctx *ctx, TileArgs a, bool safe, hipStream_t stream
     // spreads the unfinished blocks of a window over the lists; where nothing is expected to be unfinished (the
     // finish-in-place form) a wave keeps its column: the jumps cost the all-exterior tile 3 of its 23 us
     // (profiles/r03/light_path_ab.txt).
-    s.col_period = inline_todo ? 0u : ctx->opt[MBK_OPT_SCAN_COL_PERIOD];
+    // (row strips wrap nothing: the column jump below counts 8x8 block columns, so it stays off with them -- strip implies
+    // inline_todo today; the second condition keeps that true should the two ever be decoupled)
+    s.col_period = (inline_todo || strip) ? 0u : ctx->opt[MBK_OPT_SCAN_COL_PERIOD];
     if (s.xcd_map) s.col_jump = 32u * (((a.blocks_x / 32u) * 5u / 16u) | 1u);
     else s.col_jump = std::max(1u, a.blocks_x * 5u / 16u);
     if (s.col_jump >= a.blocks_x) s.col_jump = 0u, s.col_period = 0u;
@@ -951,7 +1013,7 @@ static int launch_tile(mbk_ctx *ctx, const mbk_view *v, uint32_t mrd, uint32_t f
             // us, scan 24).  heavy_share = 0 forces "group", 65536 forces "scan".
             if (kernel == MBK_KERNEL_DEFAULT && (uint64_t)((a.ncols + 7u) / 8u) * ((a.nrows + 7u) / 8u) < 16384u)
                 return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream);
-            const double share = window_heavy_share(a);
+            const double share = window_heavy_share(ctx, a);
             if (kernel == MBK_KERNEL_DEFAULT &&
                 (share * 65536.0 > (double)ctx->opt[MBK_OPT_HEAVY_SHARE] || ctx->opt[MBK_OPT_HEAVY_SHARE] == 0u))
                 return launch_blocks(ctx, a, MBK_KERNEL_GROUP, safe, f32, stream, fuse, counts_unwanted, fused);
@@ -1297,7 +1359,7 @@ static bool view_outside_circle2(const mbk_view *v, bool f32)
     return rmin2 >= 4.0 * (1.0 + (f32 ? 1e-4 : 1e-8));
 }
 
-static double view_probe_share(const mbk_view *v) { return window_heavy_share(view_window_args(v)); }
+static double view_probe_share(mbk_ctx *ctx, const mbk_view *v) { return window_heavy_share(ctx, view_window_args(v)); }
 
 // enqueue kernel + reduction + D2H of one tile on a slot's stream (no host synchronisation)
 static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mrd, uint32_t flags,
@@ -1357,7 +1419,7 @@ static int submit_view(mbk_ctx *ctx, Slot &sl, const mbk_view *view, uint32_t mr
     // wasted 0.3 ms of the copy engine beside its own 2 ms kernel, a non-uniform one that was not takes the old path in
     // mbk_wait.  Either way the caller is told by the stats whether h_bytes matters.
     bool lazy_deferred = false;
-    if (lazy) lazy_deferred = view_probe_share(view) == 0.0;
+    if (lazy) lazy_deferred = view_probe_share(ctx, view) == 0.0;
     if (wb && !lazy_deferred) MBK_HIP(ctx, hipMemcpyAsync(h_bytes, sl.d_bytes, px, hipMemcpyDeviceToHost, sl.stream));
     if (wc) MBK_HIP(ctx, hipMemcpyAsync(h_counts, sl.d_counts, px * sizeof(int32_t), hipMemcpyDeviceToHost, sl.stream));
     MBK_HIP(ctx, hipEventRecord(sl.ev_c1, sl.stream));
@@ -1831,7 +1893,7 @@ int mbk_worker_run(mbk_ctx *ctx, const char *addr, uint16_t port, uint64_t max_t
     ops.release = ctx_release;
     ops.on_tile = nullptr;
     std::string err;
-    const int rc = mbkf::run(&ops, addr, port, max_tiles, senders, report, &err, (uint32_t)MBK_SLOTS);
+    const int rc = mbkf::run(&ops, addr, port, max_tiles, senders, report, &err, (uint32_t)MBK_WORKER_DEPTH);
     if (rc != MBK_OK) {
         // a backend failure left its own message on the ctx; keep it, prefixed
         const std::string inner = ctx->err;

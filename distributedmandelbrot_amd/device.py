@@ -72,6 +72,7 @@ class MandelbrotDevice:
     """One mbk_ctx == one GPU.  Not thread-safe: use one host thread per instance."""
 
     SLOTS = L.MBK_SLOTS   # tiles in flight of the host-buffer API (submit_* / wait)
+    WORKER_DEPTH = L.MBK_WORKER_DEPTH   # what the worker loops keep in flight (include/mbk.h)
 
     def __init__(self, device: int = 0):
         self._lib = L.load()

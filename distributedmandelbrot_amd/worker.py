@@ -378,7 +378,7 @@ def run_pipelined(addr: str, port: int, device_index: int = 0, log: Callable[...
     from .device import MandelbrotDevice
     own = device is None
     dev = device if device is not None else MandelbrotDevice(device_index)
-    nslots = int(getattr(dev, "SLOTS", 2))
+    nslots = int(getattr(dev, "WORKER_DEPTH", getattr(dev, "SLOTS", 2)))   # MBK_WORKER_DEPTH = 3 of the MBK_SLOTS = 4
     nbuf = senders + nslots
     free: "queue.Queue" = queue.Queue()
     for _ in range(nbuf):

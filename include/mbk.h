@@ -208,6 +208,10 @@ int mbk_view_compute_smooth(mbk_ctx *ctx, const mbk_view *view, uint32_t mrd, ui
  * statistics arrive; (3) every other tile is copied as usual.  h_bytes of a tile reported uniform is unspecified.
  */
 #define MBK_SLOTS 4
+/* Tiles the worker loops (mbk_worker_run, worker.run_pipelined) keep in flight on one ctx: the measured-best depth of the
+ * host-buffer pipeline (profiles/r05/level16.log: level 16 at 2 / 3 / 4 in flight = 2 235 / 2 326 / 2 262 tiles/s, with
+ * MBK_LAZY_UNIFORM 4 400 / 4 603 / 4 331); MBK_SLOTS is the capacity a caller of mbk_*_submit may use. */
+#define MBK_WORKER_DEPTH 3
 int mbk_datachunk_submit(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
                          uint32_t index_imag, uint8_t *h_bytes, int32_t *h_counts);
 int mbk_datachunk_submit_ex(mbk_ctx *ctx, int slot, uint32_t level, uint32_t mrd, uint32_t index_real,
@@ -278,10 +282,11 @@ enum mbk_option {
                               above probe_steps leaves the middle class empty = the two-class order.  Measured on cfg2
                               (profiles/r03): 6 -> 581.8 us per launch, off -> 577.8: the light blocks are dispatch-bound
                               and must stay interleaved with the boundary blocks, so the default is off */
-    MBK_OPT_PREPASS_OVERLAP, /* asm/group: run the dispatch-order pre-pass (memset + classify, 13 us on cfg2) on an auxiliary
-                              stream, into one of two alternating lists, so that it overlaps the PREVIOUS launch's tile
-                              kernel on the caller's stream (the tile kernel waits for its list through an event): 0, [1], 2 = the
-                              same with the auxiliary stream at the highest priority the device offers */
+    MBK_OPT_PREPASS_OVERLAP, /* asm/group: run the dispatch-order pre-pass (one classify kernel, 13 us on cfg2) on an auxiliary
+                              stream, into one of three dispatch lists used in turn, so that it overlaps the PREVIOUS launches' tile
+                              kernels on the caller's stream (the tile kernel waits for its list through an event): 0 = on the
+                              caller's stream, in order (no second queue, no event; +4..5 us per cfg2 launch back to back), [1],
+                              2 = as 1 with the auxiliary stream at the highest priority the device offers */
     MBK_OPT_EXACT_LONG,    /* group / scan pass 2: cap on exact_steps for the blocks that run 16-step groups (classified as
                               interior, where hardly any lane escapes early -- and one that does costs a trip plus the
                               block's single fix-up): [0] = no per-step prologue for them .. 4096 (cfg2 +0.4 %, inset +0.5 %) */
@@ -310,8 +315,10 @@ enum mbk_option {
     MBK_OPT_M_LATE,        /* order 3: boundary blocks (centre pixel gone within the probe's 32 steps) whose centre escapes at
                               step >= this value open the dispatch order, before the interior blocks: the ~200 of them that
                               hold a never-escaping pixel run as long as an interior block and used to start a few microseconds
-                              before the dispatchers ran dry (csrc/mbk_units.h): 0 (off: H, M, V), 4..31 [8].  Changes when a
-                              block is computed, never what is stored */
+                              before the dispatchers ran dry (csrc/mbk_units.h): 0 (off: H, M, V), 1..65536 [8] -- a value above
+                              MBK_OPT_PROBE_STEPS leaves the class empty (the probe reports no later step); the heavy-first
+                              list of the launches the units kernel does not serve uses it when it lies in 2..probe_steps.
+                              Changes when a block is computed, never what is stored */
     MBK_OPT_H_SETTLED,     /* order 3, with the cycle test only: interior blocks whose probe orbit is within 10^-k of settled (min over p of
                               |z_32 - z_(32-p)|^2 of the centre pixel) retire within a few checks, the others run (nearly) all
                               steps; the settled ones are dispatched behind the others, so that the last interior blocks to

@@ -18,3 +18,20 @@ trace() { name=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --sta
   f=$(find "$OUT/trace_$name" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv" && echo "-- $name" && cut -d, -f1-6 "$f" | head -6; rm -rf "$OUT/trace_$name"; }
 # one PMC pass (no tracing) of bench.py: pmcrun NAME "COUNTERS" bench-args...
 pmcrun() { name=$1; counters=$2; shift 2; (cd /tmp && timeout 600 rocprofv3 --pmc $counters --output-format csv -d "$OUT/pmc_$name" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras "$@" > "$OUT/pmc_$name.log" 2>&1); line "$OUT/pmc_$name.log"; }
+# the legs of a default line that the driver's record is judged on (round 6)
+legs() { python - "$1" <<'PY'
+import json,sys
+try:
+    r=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); ro=r["roofline"]
+    cy=r.get("cycle_detection") or {}; tw=r.get("two_streams") or {}; su=r.get("sustained") or {}; xb=r.get("xcd_balance_opt_in") or {}; ee=r.get("end_to_end") or {}
+    print(f"     headline {r['value']:.1f} G/s {r['ms_per_step']:.4f} ms | per-launch pass avg {(ro.get('kernel_ms_avg_per_launch_pass') or 0):.4f} med {ro.get('kernel_ms_median',0):.4f} min {ro['kernel_ms_min']:.4f} (region avg {ro['kernel_ms_avg']:.4f}) | submit {r['config'].get('host_submit_us_per_launch')} us")
+    print(f"     cycle leg {cy.get('ms_per_step')} ms (events {cy.get('kernel_ms_avg')}, steps_run {cy.get('steps_run')}, submit {cy.get('host_submit_us_per_launch')} us) | two_streams {tw.get('ms_per_step')} ms ratio {tw.get('ratio_to_headline_value')}")
+    if su: print(f"     sustained {su.get('value')} G/s {su.get('ms_per_step')} ms x{su.get('steps_run')} frac {su.get('roofline_frac')} start {su.get('start')} middle {su.get('middle')} end {su.get('end')}")
+    if xb: print(f"     xcd_balance_opt_in {xb.get('value')} ratio {xb.get('ratio_to_headline_value')}")
+    if ee: print("     end_to_end", {k: round(v, 1) for k, v in ee.items() if k.startswith("tiles_per_s")})
+    for k, v in (r.get("configs") or {}).items(): print(f"     {k}: {v.get('value')} G/s {v.get('ms_per_step')} ms x{v.get('steps_run', v.get('steps'))} frac {(v.get('roofline') or {}).get('frac')} verified {(v.get('output_verified') or {}).get('verified')} {v.get('error','')}")
+    print("     verified", (r.get("output_verified") or {}).get("verified"), "versions", r["config"].get("versions"), "smi", r["config"].get("smi_around_timed_region"))
+except Exception as e:
+    print("  legs FAILED", sys.argv[1], e)
+PY
+}

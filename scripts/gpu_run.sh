@@ -53,6 +53,28 @@ print("     t(ms):MHz:probe ms  " + "  ".join(f"{t:.0f}:{m:.0f}:{d:.2f}" for t,m
 PY
       done;;
   headline) b cfg2_default;;
+  burst) for C in ${ARG:-0}; do timeout 300 python scripts/burst_probe.py $C 2>&1 | grep -v amdgpu.ids | tee "$OUT/burst_probe_$C.txt"; done;;
+  classes) # per-class instruction table of a units launch: classes:W,cycle[,m_late,h_settled] ...
+      hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I. -o /tmp/units_classes profiles/microbench/units_classes.hip 2> "$OUT/build_units_classes.log"
+      C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"
+      C2="SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+      for A in ${ARG:-cfg2,0 cfg2,1}; do N=units_classes_${A//,/_}
+        timeout 300 /tmp/units_classes ${A//,/ } > "$OUT/$N.txt" 2>&1
+        (cd /tmp && timeout 900 rocprofv3 --pmc $C1 --output-format csv -d "$OUT/pmc_${N}_a" -o p -- /tmp/units_classes ${A//,/ } > "$OUT/pmc_${N}_a.log" 2>&1)
+        (cd /tmp && timeout 900 rocprofv3 --pmc $C2 --output-format csv -d "$OUT/pmc_${N}_b" -o p -- /tmp/units_classes ${A//,/ } > "$OUT/pmc_${N}_b.log" 2>&1)
+        python scripts/pmc_summary.py "$OUT/${N}_pmc_by_kernel.json" "$OUT/pmc_${N}_a" "$OUT/pmc_${N}_b" --match class_units_kernel > /dev/null
+        python scripts/class_table.py "$OUT/$N.txt" "$OUT/${N}_pmc_by_kernel.json" | tee "$OUT/class_table_${A//,/_}.txt"
+        rm -rf "$OUT"/pmc_${N}_?
+      done;;
+  anyorder) hipcc --offload-arch=gfx950 -O3 -o /tmp/anyorder profiles/microbench/anyorder.hip 2> "$OUT/build_anyorder.log" && timeout 120 /tmp/anyorder > "$OUT/anyorder.txt" 2>&1; cat "$OUT/anyorder.txt";;
+  driverline) # the driver's exact command (round 6), ARG times; driverline:N[:extra bench args with commas for spaces]
+      N=${ARG%%:*}; X=${ARG#*:}; [ "$X" = "$ARG" ] && X=""; for rep in $(seq 1 ${N:-1}); do
+        T0=$(date +%s.%N); python bench.py --gpus 1 --steps 20 --warmup 5 ${X//,/ } > "$OUT/bench_driverline_$rep.log" 2>&1; T1=$(date +%s.%N)
+        line "$OUT/bench_driverline_$rep.log"; legs "$OUT/bench_driverline_$rep.log"; echo "     wall $(python -c "print(round($T1 - $T0, 2))") s" | tee "$OUT/driverline_$rep.time"; done;;
+  prevline) # the same command on the tree under .ab/prev (an earlier commit, built there)
+      for rep in $(seq 1 ${ARG:-1}); do
+        python .ab/prev/bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_prevline_$rep.log" 2>&1
+        line "$OUT/bench_prevline_$rep.log"; legs "$OUT/bench_prevline_$rep.log"; done;;
   balance) # MBK_OPT_XCD_BALANCE on (default) / off, same box: the queue job (4 tiles in flight) and the own-mode legs of cfg2 and DataChunk (1,0,0)
       for rep in 1 2; do
         b queue_n1_balance_$rep --shard queue --no-cpu-baseline

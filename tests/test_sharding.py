@@ -408,13 +408,28 @@ def test_real_bench_default_line_pins_its_outputs_and_shows_every_config():
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["output_verified"]["verified"] is True, rec["output_verified"]
     assert rec["cycle_detection"]["output_verified"]["verified"] is True
-    assert rec["config"]["xcd_balance"].startswith("1 for this leg only")
+    # round 6: the headline runs the library's defaults (the cycle test is the only option the leg changes) ...
+    assert rec["config"]["xcd_balance"] == "0 (library default)" and rec["config"]["options"] == {}
+    assert rec["xcd_balance_opt_in"]["value"] > 1000.0 and rec["xcd_balance_opt_in"]["steps_run"] >= 20
+    # ... and the line explains itself: an event-timed cycle leg of >= 50 ms, the host's share, a >= 1 s leg with clock / power
+    cyc = rec["cycle_detection"]
+    assert cyc["steps"] == 20 and cyc["steps_run"] >= 20 and cyc["steps_run"] * cyc["kernel_ms_avg"] >= 45.0
+    assert 0.9 < cyc["kernel_ms_avg"] / cyc["ms_per_step"] <= 1.0 and 0.0 < cyc["host_submit_us_per_launch"] < 500.0
+    assert 0.0 < rec["config"]["host_submit_us_per_launch"] < 500.0
+    sus = rec["sustained"]
+    assert "error" not in sus and sus["seconds"] >= 0.95 and 0.85 < sus["ratio_to_headline_value"] < 1.15 and 0.3 < sus["roofline_frac"] < 0.66
+    assert rec["two_streams"]["steps_run"] >= 20 and rec["two_streams"]["ratio_to_headline_value"] > 0.9
+    assert rec["roofline"]["kernel_ms_avg_per_launch_pass"] < 1.1 * rec["roofline"]["kernel_ms_avg"]    # (round 5: 1.22 -- a cold clock)
+    assert rec["config"]["versions"]["rocm"] and rec["config"]["versions"]["hip_runtime"]
     cfgs = rec["configs"]
     assert set(cfgs) == {"cfg3", "cfg5", "chunk_l1", "cfg4_band"}, cfgs.get("error")
     for name, c in cfgs.items():
         assert "error" not in c, (name, c)
         assert c["output_verified"]["verified"] is True, (name, c["output_verified"])
         assert c["value"] > 1000.0 and 0.2 < c["roofline"]["frac"] < 0.66, (name, c["value"], c["roofline"]["frac"])
+        assert c["steps_run"] >= c["steps"] and c["steps_run"] * c["roofline"]["kernel_ms_avg"] >= 45.0, (name, c["steps_run"])
     assert cfgs["cfg4_band"]["dtype"] == "f32" and cfgs["cfg3"]["pixel_iterations_per_step"] == 65146485486
     e2e = rec["end_to_end"]
     assert e2e["slots"] == 4 and e2e["tiles_per_s_all_slots_in_flight_lazy_uniform"] > e2e["tiles_per_s_synchronous"]
+    assert e2e["worker_depth"] == 3 and e2e["tiles_per_s_three_in_flight_lazy_uniform"] > e2e["tiles_per_s_synchronous"]
+    assert e2e["host_answered_tiles"] == 32      # level 16: the corners of [-2, 2]^2 outside |c| = 2
