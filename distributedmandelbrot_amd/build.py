@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libmbk_hip.so")
 SOURCES = [os.path.join(CSRC, "mbk_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "mbk_kernels.h"), os.path.join(CSRC, "mbk_refill.h"), os.path.join(CSRC, "mbk_loops.inc"), os.path.join(CSRC, "mbk_persist.h"), os.path.join(CSRC, "mbk_scan.h"), os.path.join(CSRC, "mbk_units.h"), os.path.join(CSRC, "mbk_feeder.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "mbk_kernels.h"), os.path.join(CSRC, "mbk_refill.h"), os.path.join(CSRC, "mbk_loops.inc"), os.path.join(CSRC, "mbk_persist.h"), os.path.join(CSRC, "mbk_scan.h"), os.path.join(CSRC, "mbk_units.h"), os.path.join(CSRC, "mbk_spill.h"), os.path.join(CSRC, "mbk_feeder.h"),
                   os.path.join(os.path.dirname(HERE), "include", "mbk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]

@@ -22,6 +22,7 @@
 #include "mbk_persist.h"
 #include "mbk_scan.h"
 #include "mbk_units.h"
+#include "mbk_spill.h"
 #include "mbk_feeder.h"
 
 using mbk::Axis;
@@ -66,6 +67,12 @@ struct StreamScratch {
     bool cursors_dirty = false;      // a scan launch failed after its cursor sets were assigned: clear both next time
     uint32_t *h_hint = nullptr;   // pinned, written by the kernels of the last launch on this stream:
                                   // [0] longest deferred list (scan pass 2), [1] share of heavy blocks x 65536
+    // SPILL (mbk_spill.h): the slots of the spilled lanes (state, meta), the per-block counts, the chunk sums / offsets and the
+    // total of the prefix sum, the compacted list of slots
+    void *d_spill_z = nullptr;
+    uint32_t *d_spill_meta = nullptr, *d_spill_cnt = nullptr, *d_spill_chunks = nullptr, *d_spill_src = nullptr;
+    unsigned long long *d_spill_total = nullptr;
+    size_t spill_cap_slots = 0, spill_cap_blocks = 0;   // capacities (slots of 16 bytes of state; blocks)
     ReduceSlot *d_red = nullptr;  // mbk_reduce_counts on this (caller) stream: its own partial results, so that a
     ReduceSlot *h_red = nullptr;  // reduction on a caller stream never shares a buffer with a tile in flight on a slot
     // kernel "units": the shares of the eight XCDs (mbk_units.h).  Launch number c (1-based) writes its time stamps into
@@ -114,6 +121,8 @@ struct mbk_ctx {
                                             // that leave room for 4 x k workgroups per CU (k = index; 0 = no padding)
     // the host probe of the last window (window_heavy_share): one submit asks for it up to three times -- the copy decision of
     // MBK_LAZY_UNIFORM, the kernel choice, the units rule -- and all three must rest on the same evaluation
+    uint32_t spill_launches = 0;              // launches that ran with the SPILL second pass (MBK_INFO_SPILL)
+    hipStream_t last_spill_stream = nullptr;  // ... and the stream of the last one
     struct ProbeKey { Axis re, im; uint32_t col0, row0, ncols, nrows; } probe_key = {};
     double probe_share = 0.0;
     bool probe_valid = false;
@@ -283,6 +292,12 @@ static void free_scratch(StreamScratch &sc)
     if (sc.aux) (void)hipStreamDestroy(sc.aux);
     if (sc.d_ctl) (void)hipFree(sc.d_ctl);
     if (sc.d_queues) (void)hipFree(sc.d_queues);
+    if (sc.d_spill_z) (void)hipFree(sc.d_spill_z);
+    if (sc.d_spill_meta) (void)hipFree(sc.d_spill_meta);
+    if (sc.d_spill_cnt) (void)hipFree(sc.d_spill_cnt);
+    if (sc.d_spill_chunks) (void)hipFree(sc.d_spill_chunks);
+    if (sc.d_spill_src) (void)hipFree(sc.d_spill_src);
+    if (sc.d_spill_total) (void)hipFree(sc.d_spill_total);
     if (sc.d_cursors) (void)hipFree(sc.d_cursors);
     if (sc.d_entries) (void)hipFree(sc.d_entries);
     if (sc.h_hint) (void)hipHostFree(sc.h_hint);
@@ -571,6 +586,48 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         a.ngrid = grid.x;
         a.order_mid = mid_first ? 2u : (ctx->opt[MBK_OPT_PROBE_MID] <= probe_steps ? 1u : 0u);
     }
+    // SPILL (round 6; mbk_kernels.h: block_pixel_spill, mbk_spill.h): the launches the units kernel does not serve -- deep zooms:
+    // little light area, long orbits -- with single-wave workgroups, 16-step groups (fp64) and counts / bytes as outputs, when
+    // the depth and the size are worth a second pass (MBK_OPT_SPILL_MIN_MRD, MBK_OPT_SPILL_MIN_WORK: a fill + four small kernels
+    // ~ 30 us -- a 128-row band of cfg3 lasts 200 us) and a checkpoint fits (the per-step prologue + the first checkpoint + 64
+    // steps).  Slot numbers are 32 bits, a lane's step count 26.
+    StreamScratch *spill_sc = nullptr;
+    const uint32_t spill_first = ctx->opt[MBK_OPT_SPILL_FIRST], spill_lanes = ctx->opt[MBK_OPT_SPILL_LANES];
+    const bool spill = !units && a.order != nullptr && order_mode >= 2u && kernel == MBK_KERNEL_GROUP && !safe && a.smooth == nullptr && wpw == 1u &&
+                       (a.counts || a.bytes) && spill_first != 0u && (f32 || ctx->opt[MBK_OPT_GROUP_STEPS] == 16u) &&
+                       (uint32_t)a.mrd >= ctx->opt[MBK_OPT_SPILL_MIN_MRD] && (uint32_t)a.mrd < (1u << 26) &&
+                       ((uint64_t)grid.x * (uint32_t)a.mrd) >> ctx->opt[MBK_OPT_SPILL_MIN_WORK] != 0ull &&
+                       (uint64_t)a.mrd > (uint64_t)ctx->opt[MBK_OPT_EXACT_STEPS] + spill_first + 66u &&
+                       (uint64_t)grid.x * spill_lanes < (1ull << 32) && a.fast_bx_end > 0u && a.fast_by_end > 0u;
+    if (spill) {
+        StreamScratch *sc = order_sc;
+        const size_t slots = (size_t)grid.x * spill_lanes, nchunks = (grid.x + mbk::kSpillChunk - 1u) / mbk::kSpillChunk;
+        if (slots > sc->spill_cap_slots || grid.x > sc->spill_cap_blocks) {
+            MBK_HIP(ctx, hipStreamSynchronize(stream));   // the old buffers may still be in use
+            for (void **q : {&sc->d_spill_z, (void **)&sc->d_spill_meta, (void **)&sc->d_spill_cnt, (void **)&sc->d_spill_chunks,
+                             (void **)&sc->d_spill_src, (void **)&sc->d_spill_total}) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+            sc->spill_cap_slots = sc->spill_cap_blocks = 0;
+            MBK_HIP(ctx, hipMalloc(&sc->d_spill_z, slots * 16u));          // (zr, zi) as two doubles; two floats use half of it
+            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_meta, slots * sizeof(uint32_t)));
+            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_src, slots * sizeof(uint32_t)));
+            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_cnt, (size_t)grid.x * sizeof(uint32_t)));
+            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_chunks, (nchunks * mbk::kSpillLevels + 1u) * sizeof(uint32_t)));
+            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_total, sizeof(unsigned long long)));
+            sc->spill_cap_slots = slots;
+            sc->spill_cap_blocks = grid.x;
+        }
+        a.spill_first = spill_first;
+        a.spill_lanes = spill_lanes;
+        a.spill_win_shift = ctx->opt[MBK_OPT_SPILL_CYC_SHIFT];
+        a.spill_z = sc->d_spill_z;
+        a.spill_meta = sc->d_spill_meta;
+        a.spill_cnt = sc->d_spill_cnt;
+        MBK_HIP(ctx, hipMemsetAsync(sc->d_spill_cnt, 0, (size_t)grid.x * sizeof(uint32_t), stream));
+        spill_sc = sc;
+    }
     // MBK_OPT_WAVE_LIMIT: unused dynamic LDS caps the resident waves per SIMD (single-wave workgroups only)
     const uint32_t lds = wpw == 1u ? ctx->wave_limit_lds[ctx->opt[MBK_OPT_WAVE_LIMIT] & 7u] : 0u;
     if (units && a.order) {
@@ -611,6 +668,15 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
         else MBK_LAUNCH_UNITS(double, 16, false);
 #undef MBK_LAUNCH_UNITS
     } else
+    if (spill_sc && f32 && cyc)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8, true, true>), grid, block, lds, stream, a);
+    else if (spill_sc && f32)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<float, true, 8, false, true>), grid, block, lds, stream, a);
+    else if (spill_sc && cyc)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16, true, true>), grid, block, lds, stream, a);
+    else if (spill_sc)
+        hipLaunchKernelGGL((mbk::tile_asm_kernel<double, true, 16, false, true>), grid, block, lds, stream, a);
+    else
     if (f32 && safe)
         hipLaunchKernelGGL((mbk::tile_asm_kernel<float, false, 0>), grid, block, lds, stream, a);
     else if (f32 && kernel == MBK_KERNEL_ASM)
@@ -645,6 +711,31 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     if (order_slot >= 0 && order_overlap) {   // list `order_slot` is busy until this tile kernel has finished
         MBK_HIP(ctx, hipEventRecord(order_sc->ev_done[order_slot], stream));
         order_sc->done_valid[order_slot] = true;
+    }
+    if (spill_sc) {
+        // the second pass: compact the blocks' spilled lanes into one list (chunk sums, their scan, the expansion), then run them
+        StreamScratch *sc = spill_sc;
+        const uint32_t nchunks = (grid.x + mbk::kSpillChunk - 1u) / mbk::kSpillChunk;
+        hipLaunchKernelGGL(mbk::spill_count_kernel, dim3(nchunks), dim3(mbk::kSpillChunk), 0, stream, sc->d_spill_cnt, grid.x, nchunks, sc->d_spill_chunks);
+        hipLaunchKernelGGL(mbk::rle_scan_kernel, dim3(1), dim3(1024), 0, stream, sc->d_spill_chunks, nchunks * mbk::kSpillLevels, sc->d_spill_total);
+        hipLaunchKernelGGL(mbk::spill_expand_kernel, dim3(nchunks), dim3(mbk::kSpillChunk), 0, stream, sc->d_spill_cnt, grid.x, nchunks,
+                           sc->d_spill_chunks, spill_lanes, sc->d_spill_src);
+        // grid: an upper bound (the number of lanes is known on the device only), strided
+        const uint32_t nwg = (uint32_t)std::min<uint64_t>(((uint64_t)grid.x * spill_lanes + 63u) / 64u, 16384u);
+        // (fewer resident waves per SIMD for this pass -- through unused LDS, as MBK_OPT_WAVE_LIMIT -- were tried: 2 / 3 per SIMD cost
+        // 0.1 / 0.05 ms of its 0.64 ms; what halved it was the order of the list, latest checkpoint first: profiles/r06/spill_ab.txt)
+        const uint32_t lds2 = 0u;
+        if (f32 && cyc)
+            hipLaunchKernelGGL((mbk::tile_spill_kernel<float, true>), dim3(nwg), dim3(64), lds2, stream, a, sc->d_spill_src, sc->d_spill_total, nwg);
+        else if (f32)
+            hipLaunchKernelGGL((mbk::tile_spill_kernel<float, false>), dim3(nwg), dim3(64), lds2, stream, a, sc->d_spill_src, sc->d_spill_total, nwg);
+        else if (cyc)
+            hipLaunchKernelGGL((mbk::tile_spill_kernel<double, true>), dim3(nwg), dim3(64), lds2, stream, a, sc->d_spill_src, sc->d_spill_total, nwg);
+        else
+            hipLaunchKernelGGL((mbk::tile_spill_kernel<double, false>), dim3(nwg), dim3(64), lds2, stream, a, sc->d_spill_src, sc->d_spill_total, nwg);
+        MBK_HIP(ctx, hipGetLastError());
+        ++ctx->spill_launches;
+        ctx->last_spill_stream = stream;
     }
     return MBK_OK;
 }
@@ -1160,7 +1251,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
         /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u,
-        /* SCAN_STRIP */ 1u, /* CYCLE_WINDOW */ 32u};
+        /* SCAN_STRIP */ 1u, /* CYCLE_WINDOW */ 32u, /* SPILL_FIRST */ 256u, /* SPILL_LANES */ 16u, /* SPILL_MIN_MRD */ 2048u, /* SPILL_MIN_WORK */ 29u, /* SPILL_CYC_SHIFT */ 5u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1692,6 +1783,11 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_XCD_BALANCE: ok = value <= 2u; break;
         case MBK_OPT_M_LATE: ok = value <= 65536u; break;
         case MBK_OPT_H_SETTLED: ok = value <= 30u; break;
+        case MBK_OPT_SPILL_FIRST: ok = value <= 65536u && value % 32u == 0u; break;
+        case MBK_OPT_SPILL_LANES: ok = value >= 1u && value <= 32u; break;
+        case MBK_OPT_SPILL_MIN_MRD: ok = true; break;
+        case MBK_OPT_SPILL_MIN_WORK: ok = value <= 62u; break;
+        case MBK_OPT_SPILL_CYC_SHIFT: ok = value <= 31u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }
     if (!ok) return fail(ctx, MBK_ERR_INVALID, "option value out of range");
@@ -1714,6 +1810,21 @@ int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value)
             if (!best || sc.xcd_consumed > best->xcd_consumed) best = &sc;
         const int k = option - MBK_INFO_XCD_SHARE;
         *value = !best ? 0u : k < 8 ? (uint32_t)std::lround(best->xcd_f[k] * 1048576.0) : k == 8 ? best->xcd_consumed : best->xcd_issued;
+        return MBK_OK;
+    }
+    if (option == MBK_INFO_SPILL || option == MBK_INFO_SPILL + 1) {
+        *value = ctx->spill_launches;
+        if (option == MBK_INFO_SPILL) {   // lanes the last such launch handed to its second pass (waits for that launch)
+            *value = 0u;
+            for (const StreamScratch &sc : ctx->scratch)
+                if (sc.stream == ctx->last_spill_stream && sc.d_spill_total && ctx->spill_launches) {
+                    unsigned long long t = 0;
+                    MBK_HIP(ctx, hipSetDevice(ctx->device));
+                    MBK_HIP(ctx, hipStreamSynchronize(sc.stream));
+                    MBK_HIP(ctx, hipMemcpy(&t, sc.d_spill_total, sizeof(t), hipMemcpyDeviceToHost));
+                    *value = (uint32_t)std::min<unsigned long long>(t, 0xffffffffull);
+                }
+        }
         return MBK_OK;
     }
     if (option < 0 || option >= MBK_OPT_COUNT_) return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");

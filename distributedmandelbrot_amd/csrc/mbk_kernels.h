@@ -71,6 +71,14 @@ struct TileArgs {
                           // itself, so that a DataChunk needs no int32 counts in HBM at all
     uint32_t cyc_window;  // cycle test: the reference state's window grows by a quarter while shorter than this many checks,
                           // doubles from there on (0 = always doubles; mbk_loops.inc, WINDOW SCHEDULE)
+    // SPILL (round 6; block_pixel_spill below, mbk_spill.h): spill_first != 0 = the one-wave-per-block kernel hands the last few
+    // live lanes of a block over to a second pass instead of running them alone
+    uint32_t spill_first; // steps between the per-step prologue and the first checkpoint (a multiple of 32); each next one twice as far
+    uint32_t spill_lanes; // a block spills at a checkpoint when this many lanes or fewer are still alive (slots per block)
+    uint32_t spill_win_shift;  // second pass, cycle test: the first window is (steps behind the wave's lanes) >> this, in checks
+    void *spill_z;        // [block * spill_lanes + rank]: (zr, zi) of a spilled lane, as two T
+    uint32_t *spill_meta; // [block * spill_lanes + rank]: lane in the block (bits 0..5) | steps done (bits 6..31)
+    uint32_t *spill_cnt;  // [block]: lanes the block spilled | the number of its checkpoint << 8 (zeroed by the host before the launch)
 };
 
 // np.linspace sample k (numpy/_core/function_base.py): two roundings, endpoint pinned.
@@ -271,8 +279,103 @@ __device__ __forceinline__ int32_t block_pixel(const TileArgs &p, uint32_t ucol,
     return count;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SPILL (round 6).  A wave runs until its LAST lane is done.  On a deep zoom most blocks hold pixels that escape after a few
+// hundred steps next to a handful that need thousands (filaments) or never escape: cfg3 executes 1 219.8 M wave-steps for
+// 1 017.9 M wave-steps of work (lane activity 0.835, measured 0.832), and 313 000 of its 1 048 576 blocks reach step 512 with
+// 16 or fewer of their 64 lanes alive.  Re-packing the survivors inside a workgroup loses (round 4: 16x16 regions reach 0.85
+// and pay the 4-wave-workgroup penalty); a lane-refill kernel loses (round 5: its grouped test replays every group).  What is
+// left is to pack them GLOBALLY: at checkpoints -- spill_first steps after the per-step prologue, then twice as far each time --
+// a block with at most spill_lanes live lanes writes their state (zr, zi, lane, steps done) into its own slots of a list in
+// HBM and ends; a prefix sum over the blocks' counts compacts the list (no atomics: a device-scope atomic with return costs
+// 25 ns, serialised chip-wide -- profiles/r04/units_pool_ab.txt -- and a cfg3 launch would need 380 000 of them), and a second
+// kernel (tile_spill_kernel, mbk_spill.h) runs the listed lanes 64 to a wave from where they stopped: escape_steps_tail resumes
+// from any state, and the deferred replay keeps the grouped test cheap there (a lane that trips just leaves).  Model on the
+// exact counts (scripts/spill_model.py): cfg3 1 219.8 -> 1 106.4 + 23.3 M wave-steps (-7.4 %) with checkpoints 256, 512, ... and
+// 16 lanes.  Exact by construction: the same recurrence from the same state; the cycle test starts afresh at every checkpoint
+// (any schedule of its reference state is exact).  Interior blocks only (regular coordinates, no lane outside the window).
+// The caller stores nothing for a spilled lane (the second pass does).
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct SpillPair;
+template <> struct SpillPair<double> { using type = double2; };
+template <> struct SpillPair<float> { using type = float2; };
+constexpr int32_t kSpilled = -2;   // count of a lane whose pixel the second pass finishes
+
+template <typename T, int kGroup, bool kCycle>
+__device__ __forceinline__ void block_pixel_spill(const TileArgs &p, uint32_t ucol, uint32_t urow, uint32_t lx, uint32_t ly,
+                                                  bool long_groups, uint32_t block_index)
+{
+    const uint32_t lc = ucol + lx, lr = urow + ly;
+    const T cr = (T)((double)(p.col0 + lc) * p.re.step + p.re.start);
+    const T ci = (T)((double)(p.row0 + lr) * p.im.step + p.im.start);
+    bool risky = false;
+    if (p.ring_possible != 0u) {   // (block_pixel: a wave touching the |c| = 2 ring takes the per-step loop)
+        const T c2 = cr * cr + ci * ci;
+        const T margin = sizeof(T) == 8 ? (T)1e-9 : (T)1e-3;
+        risky = __ballot(__builtin_fabs((double)(c2 - (T)4)) < (double)margin) != 0ull;
+    }
+    int32_t count;
+    if (risky) {
+        count = escape_count_asm<true>(cr, ci, p.mrd);
+    } else {
+        T zr = cr, zi = ci, a = zr * zr, b = zi * zi, m = 0;
+        int32_t cnt = 0;
+        const uint32_t total = p.mrd > 1 ? (uint32_t)p.mrd - 1u : 0u;
+        const uint32_t ex = (kGroup >= 16 && long_groups) ? p.exact_steps_long : p.exact_steps;
+        const uint32_t first = total < ex ? total : ex;
+        escape_steps_asm<true>(cr, ci, zr, zi, a, b, m, cnt, 0u, first);
+        uint32_t n = first, seg = p.spill_first, level = 0u;     // wave-uniform
+        bool spilled = false;
+        // The stretches run WITHOUT the deferred replay at their ends: a lane that tripped a group test stays pending -- frozen,
+        // outside every later stretch (cnt != 0) -- and ONE fix-up behind the loop serves the whole block, as in block_pixel
+        // (the first build replayed at every checkpoint: up to 16 exact steps x 9 slots per stretch in which a lane escaped,
+        // which on a deep zoom is every stretch of every block -- it cost what the spill saved, profiles/r06/spill_ab.txt).
+        while (n < total) {
+            if (__ballot(cnt == 0) == 0ull) break;   // every lane has escaped or been retired
+            // the next checkpoint -- unless fewer than 64 steps would be left behind it: then straight to the end
+            const uint32_t stop = (total - n > seg + 64u) ? n + seg : total;
+            if (cnt == 0) {
+                if (kGroup >= 16 && long_groups) escape_steps_tail<16, kCycle, false>(cr, ci, zr, zi, a, b, m, cnt, n, stop, p.cyc_window);
+                else escape_steps_tail<8, kCycle, false>(cr, ci, zr, zi, a, b, m, cnt, n, stop, p.cyc_window);
+            }
+            n = stop;
+            if (n >= total) break;
+            const unsigned long long alive = __ballot(cnt == 0);
+            const uint32_t k = (uint32_t)__popcll(alive);
+            if (k == 0u) break;
+            if (k <= p.spill_lanes) {
+                if (cnt == 0) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(alive >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)alive, 0u));
+                    const size_t slot = (size_t)block_index * p.spill_lanes + rank;
+                    typename SpillPair<T>::type z;
+                    z.x = zr;
+                    z.y = zi;
+                    reinterpret_cast<typename SpillPair<T>::type *>(p.spill_z)[slot] = z;
+                    p.spill_meta[slot] = (ly * 8u + lx) | (n << 6);
+                    if (rank == 0u) p.spill_cnt[block_index] = k | ((level < 11u ? level : 11u) << 8);   // (11 = kSpillLevels - 1)
+                    spilled = true;
+                }
+                break;
+            }
+            // the next checkpoint lies twice as far behind the prologue (3/2 and 4/3 in turn -- 256, 384, 512, 768, ... -- was
+            // tried: strict +-0, cycle leg +6 %: every checkpoint restarts the cycle test's window; profiles/r06/spill_ab.txt)
+            seg = n - first;
+            ++level;
+        }
+        escape_fixup(cr, ci, zr, zi, a, b, m, cnt);   // (a spilled lane has cnt == 0: not pending)
+        count = spilled ? kSpilled : ((kCycle && cnt == -1) ? 0 : cnt);   // -1: retired by the cycle test = never escapes
+    }
+    if (count != kSpilled) {
+        const size_t ubase = (size_t)(urow + p.out_row0) * p.out_pitch + ucol + p.out_col0;
+        const uint32_t loff = ly * p.out_pitch + lx;
+        if (p.counts) (p.counts + ubase)[loff] = count;
+        if (p.bytes) (p.bytes + ubase)[loff] = quantise(count, p);
+    }
+}
+
 // Kernels "asm" (kGroup = 0) and "group": one 8x8 block per wave, blockDim / 64 blocks per workgroup.
-template <typename T, bool kFmaDouble, int kGroup = 0, bool kCycle = false>
+// kSpill (single-wave workgroups, kFmaDouble, no smooth output): interior blocks go through block_pixel_spill.
+template <typename T, bool kFmaDouble, int kGroup = 0, bool kCycle = false, bool kSpill = false>
 __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -316,6 +419,9 @@ __global__ __launch_bounds__(256) void tile_asm_kernel(TileArgs p)
     // the blocks the heavy-first probe put at the front of the dispatch order take the 16-step groups
     const bool long_groups = kGroup >= 16 && (!p.order || (blockIdx.x >= heavy_lo && blockIdx.x < heavy_lo + n_heavy));   // wave-uniform
     const bool interior = wcol < p.fast_bx_end && by < p.fast_by_end;                        // wave-uniform
+    if (kSpill && kFmaDouble && kGroup >= 8 && interior)
+        block_pixel_spill<T, kGroup, kCycle>(p, wcol * 8u, by * 8u, lane & 7u, lane >> 3, long_groups, by * p.blocks_x + wcol);
+    else
     block_pixel<T, kFmaDouble, kGroup, kCycle>(p, wcol * 8u, by * 8u, lane & 7u, lane >> 3, long_groups, interior);
 }
 

@@ -162,6 +162,14 @@ class MandelbrotDevice:
             vals.append(int(v.value))
         return {"shares": [round(v / 1048576.0, 5) for v in vals[:8]], "last_launch_read": vals[8], "units_launches": vals[9]}
 
+    def spill_info(self) -> dict:
+        """SPILL (MBK_OPT_SPILL_FIRST): lanes the last launch with a second pass handed over to it, and how many launches of
+        this context ran with one."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.mbk_get_option(self._h, L.MBK_INFO_SPILL, C.byref(a)))
+        self._check(self._lib.mbk_get_option(self._h, L.MBK_INFO_SPILL + 1, C.byref(b)))
+        return {"lanes_last_launch": int(a.value), "launches": int(b.value)}
+
     def quantise_counts(self, counts: np.ndarray, mrd: int) -> np.ndarray:
         """The device's quantiser alone (WorkerCUDA.py:96-98) on host int32 counts in [0, mrd-1]."""
         counts = np.ascontiguousarray(counts, dtype=np.int32)

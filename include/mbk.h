@@ -340,6 +340,23 @@ enum mbk_option {
                               checks and doubles from there on (long periods -- deep zooms -- need long windows): 6-7 % fewer
                               wave-steps on full-set views and shallow DataChunks, cfg3 unchanged (scripts/cycle_window_model.c).
                               0 .. 65536.  Every schedule is exact: a bitwise repeat proves the cycle whichever two steps match */
+    MBK_OPT_SPILL_FIRST,   /* group, launches the units kernel does not serve (deep zooms; fp64 with 16-step groups, fp32; counts / bytes;
+                              single-wave workgroups; dispatch order 2 or 3): SPILL (round 6, csrc/mbk_kernels.h block_pixel_spill,
+                              csrc/mbk_spill.h).  A wave runs until its last lane is done, and on a deep zoom a third of the blocks
+                              reach step ~500 with a handful of their 64 lanes alive.  At checkpoints -- this many steps after the
+                              per-step prologue, then twice as far each time -- a block with at most MBK_OPT_SPILL_LANES live lanes writes
+                              their state to a list in HBM and ends; a prefix sum compacts the list (no atomics) and a second kernel
+                              runs the listed lanes 64 to a wave from where they stopped.  Same recurrence from the same state:
+                              identical counts.  0 = off, else a multiple of 32 up to 65536 [256] */
+    MBK_OPT_SPILL_LANES,   /* SPILL: a block spills when this many lanes or fewer are alive at a checkpoint (= the slots of 20 bytes a
+                              block owns in the list: 335 MB for an 8192^2 window at 16): 1 .. 32 [16] */
+    MBK_OPT_SPILL_MIN_MRD, /* SPILL: only launches with mrd at least this deep (the second pass costs four small kernels, ~30 us,
+                              and shallow tiles have nothing to hand over): [2048] */
+    MBK_OPT_SPILL_MIN_WORK, /* SPILL: ... and only launches of at least 2^this (8x8 blocks x mrd): [29] = a 4096^2 tile at mrd 2048, 512 rows
+                              of an 8192-wide view at mrd 8192 -- launches of a millisecond and more.  0 .. 62 */
+    MBK_OPT_SPILL_CYC_SHIFT, /* SPILL with the cycle test: the second pass resumes orbits that have n steps behind them; the window of its
+                              first reference state is n >> this checks (of 8 steps) instead of 1 -- [5]: where the schedule of an
+                              unbroken run would stand (windows of ~ n / 4 steps); 31 = start at 1.  Any schedule is exact.  0 .. 31 */
     MBK_OPT_COUNT_
 };
 /* Read-only diagnostics through mbk_get_option: what hipOccupancyMaxActiveBlocksPerMultiprocessor reports for the
@@ -348,6 +365,9 @@ enum mbk_option {
 /* MBK_OPT_XCD_BALANCE = 1, of the stream that has reported most: +0..+7 the share of XCD x of the heavy list (x 2^20; an even
  * deal is 131072), +8 the number of the last launch whose time stamps were read, +9 the units launches issued. */
 #define MBK_INFO_XCD_SHARE 110
+/* SPILL (MBK_OPT_SPILL_FIRST): +0 the lanes the last launch with a second pass handed over to it (waits for that launch),
+ * +1 the number of launches of this ctx that ran with one. */
+#define MBK_INFO_SPILL 130
 int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value);
 int mbk_get_option(mbk_ctx *ctx, int option, uint32_t *value);
 

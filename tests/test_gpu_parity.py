@@ -457,6 +457,8 @@ OPTION_MATRIX = [
     ("scan", {"scan_strip": 0}), ("default", {"scan_strip": 0, "cycle_detect": 0, "scan_waves": 3}),
     ("group", {"cycle_window": 0}), ("default", {"cycle_window": 5}), ("scan", {"cycle_window": 65536, "group_steps": 8}),
     ("default", {"cycle_window": 1, "h_settled": 0, "m_late": 0}),
+    ("group", {"spill_first": 32, "spill_lanes": 32, "spill_min_mrd": 2, "spill_min_work": 0, "order": 2}), ("default", {"spill_first": 0}),
+    ("default", {"spill_first": 64, "spill_lanes": 3, "spill_min_mrd": 100, "spill_min_work": 3, "units_min_light": 65536, "cycle_detect": 0}),
 ]
 
 
@@ -483,6 +485,66 @@ def test_option_matrix_is_bit_exact(oracle, kernel, options):
             dev.set_option("scan_waves", 9)
         for view, mrd in cases:
             _check_view(dev, oracle, view, mrd, kernel=kernel)
+
+
+SPILL_OPTIONS = [{"spill_first": 256, "spill_lanes": 16}, {"spill_first": 32, "spill_lanes": 1}, {"spill_first": 32, "spill_lanes": 32},
+                 {"spill_first": 64, "spill_lanes": 5, "exact_steps": 0}, {"spill_first": 512, "spill_lanes": 8, "exact_steps": 21, "exact_long": 3},
+                 {"spill_first": 96, "spill_lanes": 16, "cycle_window": 0, "spill_cyc_shift": 31}, {"spill_first": 64, "spill_lanes": 9, "spill_cyc_shift": 0}, {"spill_first": 128, "spill_lanes": 16, "order": 2, "prepass_overlap": 0}]
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("cycle", [0, 1])
+def test_spill_second_pass_is_bit_exact(oracle, precision, cycle):
+    """SPILL (round 6, MBK_OPT_SPILL_FIRST / _LANES / _MIN_MRD; csrc/mbk_kernels.h block_pixel_spill, csrc/mbk_spill.h): blocks
+    that reach a checkpoint with a few live lanes hand them to a second pass.  Deep-zoom windows (filaments: where it pays),
+    a ragged window, a window with an offset, a full-set view forced onto the path (ring waves, blocks that are all set) --
+    every output set, checkpoints from 32 steps on, 1 .. 32 lanes, against the oracle; and the second pass really ran."""
+    from distributedmandelbrot_amd import MandelbrotDevice
+    views = [(View(-0.743648, 0.131820, 1e-5, 1e-5, 1024, 1024), 3000, None, "default", {}),
+             (View(-0.7436431, 0.1318255, 2e-7, 2e-7, 1200, 1100), 2500, (3, 5, 1101, 1027), "default", {}),      # ragged, offset
+             (View(-0.755, 0.10, 0.02, 0.02, 1024, 1024), 2048, None, "group", {}),
+             (View(-2.0, -1.5, 3.0, 3.0, 1024, 1024), 700, None, "group", {"order": 2})]                        # the |c| = 2 ring, interior blocks
+    if precision == "f32":   # (fp32 has no resolution at 1e-7: the deep windows become blocky, which the oracle reproduces)
+        views = [views[0], views[2], views[3]]
+    want = {}
+    for i, (view, mrd, window, kernel, extra) in enumerate(views):
+        want[i] = oracle.view(view.start_r, view.start_i, view.range_r, view.range_i, view.width, view.height, mrd, window=window, precision=precision)
+    for k, opts in enumerate(SPILL_OPTIONS):
+        with MandelbrotDevice(0) as dev:
+            dev.set_option("cycle_detect", cycle)
+            dev.set_option("spill_min_mrd", 2)
+            dev.set_option("spill_min_work", 0)
+            for name, value in opts.items():
+                dev.set_option(name, value)
+            for i, (view, mrd, window, kernel, extra) in enumerate(views):
+                for name, value in extra.items():
+                    dev.set_option(name, value)
+                before = dev.spill_info()["launches"]
+                wc, wb = (True, True) if (i + k) % 3 == 0 else (True, False) if (i + k) % 3 == 1 else (False, True)
+                c, b, st = dev.compute_view(view, mrd, window=window, kernel=kernel, precision=precision, want_counts=wc, want_bytes=wb)
+                oc, ob, total = want[i]
+                if wc:
+                    assert np.array_equal(c, oc), (opts, i, int((c != oc).sum()))
+                if wb:
+                    assert np.array_equal(b, ob), (opts, i)
+                assert st.pixel_iterations == total and st.never_pixels == int((oc == 0).sum())
+                info = dev.spill_info()
+                assert info["launches"] == before + 1, (opts, i, info)          # the path under test is the one that ran
+                if i == 0 and opts["spill_lanes"] >= 5:
+                    assert info["lanes_last_launch"] > 1000, (opts, i, info)     # ... and had something to do on the deep windows
+    # off by option, and off for shallow tiles by default
+    with MandelbrotDevice(0) as dev:
+        dev.set_option("spill_first", 0)
+        dev.compute_view(views[0][0], views[0][1], want_bytes=False, precision=precision)
+        assert dev.spill_info()["launches"] == 0
+    with MandelbrotDevice(0) as dev:
+        dev.compute_view(views[0][0], 4096, want_bytes=False, precision=precision)      # 2^14 blocks x 2^12 steps: under MBK_OPT_SPILL_MIN_WORK
+        assert dev.spill_info()["launches"] == 0
+        dev.set_option("spill_min_work", 0)
+        dev.compute_view(views[0][0], 1500, want_bytes=False, precision=precision)      # mrd below MBK_OPT_SPILL_MIN_MRD
+        assert dev.spill_info()["launches"] == 0
+        dev.compute_view(views[0][0], 2048, want_bytes=False, precision=precision)
+        assert dev.spill_info()["launches"] == 1
 
 
 def test_units_order_every_output_set_and_shape(oracle):
