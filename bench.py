@@ -33,7 +33,11 @@ a few gathered Python objects, on gloo (`--control nccl` exists to A/B that choi
 
 Before the W warm-up steps the clock is pre-conditioned for --ramp-ms (150 ms) with untimed launches of
 the same workload: an idle MI355X needs 50-100 ms of load to reach its sustained clock, and a 0.6 ms tile
-measured cold reads 15-20 % low.
+measured cold reads 15-20 % low.  Round 6: EVERY leg of the line gets that ramp (each one
+follows host work -- a reduction, a sha256 of 64 MiB, a sub-process -- through which the GPU idled: 20 ms of idleness
+cost the next 60 launches 8 % on average, profiles/r06/burst_probe_0.txt; round 5's cycle-test, two-stream and
+per-launch figures in the driver's 20-step run were measured that way and read 12-22 % low), and every leg beside
+the headline is repeated until it holds >= 50 ms of device time (`steps_run`; the headline times exactly --steps).
 
 Prints ONE JSON line on rank 0.  `value` = whole-job G pixel-iterations/s where a pixel's iterations
 are count if count > 0 else mrd-1, summed from the kernel's own output.
@@ -64,10 +68,17 @@ the reference's output inside this very run; the cycle-test leg carries its own.
 line only): a short strict leg of every other single-GPU BASELINE config -- cfg3 (2 launches), cfg5 (3), DataChunk (1,0,0)
 (20), cfg4 as one 16 384 x 1 024 band in fp32 (2) -- each with value, ms_per_step, roofline.frac and output_verified.
 
+Round 6 also: the headline runs the library's DEFAULT options (the cycle test is the only one the leg changes;
+MBK_OPT_XCD_BALANCE, which rounds 4-5 switched on for it, is timed as the extra object `xcd_balance_opt_in`);
+`cycle_detection` carries `kernel_ms_avg` from one pair of HIP events around its launches beside the wall-clock
+`ms_per_step`, and the host's submit time per launch; `sustained` = the headline's launches back to back for >= 1 s
+with board power and shader clock sampled through librocm_smi64 (start / middle / end); `config.versions` = ROCm, HIP
+runtime, kernel, VBIOS and firmware of the box.
+
 More extra objects at N = 1, all outside `value` (SURVEY.md 8d "reported beside it"):
 `end_to_end` -- a whole level of the reference's pyramid (level 16, mrd 1024: 256 DataChunk tiles) through the
-host-buffer API, i.e. kernel + quantise + statistics + D2H into pinned memory: tiles/s synchronous, with two / four tiles
-in flight, and with uniform tiles not copied (what the worker does); kernel median / mean / max, D2H mean;
+host-buffer API, i.e. kernel + quantise + statistics + D2H into pinned memory: tiles/s synchronous, with two / three (the
+worker loops' depth) / four tiles in flight, and with uniform tiles not copied (what the worker does); kernel median / mean / max, D2H mean;
 `queue_job` -- the N > 1 default job (--shard queue) run on this one GPU, i.e. the same-mode N = 1 point of the
 scaling curve.
 """
@@ -463,6 +474,7 @@ def extra_configs(dev, torch, gpu_index, device_info, ramp_ms=150.0):
                 else:
                     dev.launch_view(view, mrd, window=window, d_counts=d_counts.data_ptr(), stream=stream.cuda_stream, precision=precision)
 
+            sp0 = dev.spill_info() if hasattr(dev, "spill_info") else {"launches": 0}
             t_ramp = time.perf_counter()        # clock pre-conditioning, as for the headline (--ramp-ms): the legs before this
             while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:   # one left the GPU idle or on another kind of load
                 launch()
@@ -500,6 +512,14 @@ def extra_configs(dev, torch, gpu_index, device_info, ramp_ms=150.0):
                              "basis": "one pair of HIP events on the launch stream around the timed launches, elapsed / K"},
                 "output_verified": verify_output(name, d_counts, st.pixel_iterations, st.never_pixels, view, mrd, precision, window),
             }
+            try:   # SPILL (MBK_OPT_SPILL_FIRST): did the launches of this leg run with a second pass, and how many lanes did it take?
+                sp1 = dev.spill_info()
+                if sp1["launches"] > sp0["launches"]:
+                    out[name]["second_pass"] = {"lanes_per_launch": sp1["lanes_last_launch"], "share_of_pixels": sp1["lanes_last_launch"] / npx,
+                                                "what": "SPILL (include/mbk.h MBK_OPT_SPILL_FIRST, library default): blocks that reach a checkpoint "
+                                                        "with <= 16 live lanes hand them to a second kernel that runs them 64 to a wave"}
+            except Exception:   # noqa: BLE001
+                pass
             del d_counts, d_smooth
         except Exception as e:   # noqa: BLE001 -- reported, must not cost the headline
             out[name] = {"error": repr(e)}
@@ -545,16 +565,18 @@ def end_to_end(dev, level=16, mrd=1024):
 
     nslots = int(getattr(dev, "SLOTS", 2))
     pins += [dev.pinned_empty((16777216,), np.uint8) for _ in range(nslots - len(pins))]
-    t_two = in_flight(2, False)
-    t_lazy = in_flight(2, True)
-    t_three = in_flight(min(3, nslots), False)      # what the worker loops keep in flight (round 6: the measured-best depth)
-    t_three_lazy = in_flight(min(3, nslots), True)
-    t_all = in_flight(nslots, False)
-    t_all_lazy = in_flight(nslots, True)
+    def best(k, lazy):      # a pass takes 60-120 ms and the pool's boxes differ by +-5 % from one pass to the next: the better of two
+        return min(in_flight(k, lazy), in_flight(k, lazy))
+    t_two = best(2, False)
+    t_lazy = best(2, True)
+    t_three = best(min(3, nslots), False)      # what the worker loops keep in flight (round 6: the measured-best depth)
+    t_three_lazy = best(min(3, nslots), True)
+    t_all = best(nslots, False)
+    t_all_lazy = best(nslots, True)
     ks_sorted = sorted(ks)
     return {"what": f"level {level} of the reference's pyramid, mrd {mrd}: {n} DataChunk tiles (4096^2) through the host-buffer "
                     "API on one context -- kernel + quantise + statistics + D2H of the 16 MiB byte tile into pinned memory, "
-                    "library defaults (cycle test on); not part of `value`",
+                    "library defaults (cycle test on); the pipelined rates are the better of two passes each; not part of `value`",
             "tiles": n, "uniform_never_tiles": int(never), "uniform_immediate_tiles": int(imm),
             "tiles_per_s_synchronous": n / t_sync, "tiles_per_s_two_in_flight": n / t_two,
             "tiles_per_s_two_in_flight_lazy_uniform": n / t_lazy,

@@ -33,7 +33,14 @@ print(f"  bound of a perfect pipeline: sum of max(kernel, d2h) per tile = {sum(m
 nslots = dev.SLOTS
 pins = [dev.pinned_empty((16777216,), np.uint8) for _ in range(nslots)]
 tiles = [(ir, ii) for ir in range(level) for ii in range(level)]
-# host time per tile of the two calls, by kind of tile (MBK_LAZY_UNIFORM, all slots in flight)
+# host time per tile of the two calls, by kind of tile (MBK_LAZY_UNIFORM, all slots in flight) -- after one untimed pipelined pass:
+# the first tile on a slot's stream creates its scratch (dispatch lists, an auxiliary stream, events: milliseconds, once), which
+# round 5's figure for the copied tiles (446 us per submit) was mostly made of
+for i in range(n + nslots):
+    if i >= nslots:
+        dev.wait((i - nslots) % nslots)
+    if i < n:
+        dev.submit_datachunk(i % nslots, level, mrd, *tiles[i], pins[i % nslots], lazy_uniform=True)
 acc = {}
 inflight_kind = {}
 for i in range(n + nslots):
