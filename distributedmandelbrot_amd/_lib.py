@@ -28,7 +28,7 @@ KERNELS = {"default": MBK_KERNEL_DEFAULT, "simple": MBK_KERNEL_SIMPLE, "asm": MB
 # enum mbk_option (include/mbk.h), in order
 OPTIONS = {name: i for i, name in enumerate(
     ["order", "waves_per_wg", "group_steps", "exact_steps", "probe_steps", "scan_waves", "scan_xcd_map", "scan_col_period", "heavy_share",
-     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid", "prepass_overlap", "exact_long", "scan_inline", "wave_limit", "units_min_light", "xcd_balance", "m_late", "h_settled", "classify_wg", "scan_strip", "cycle_window", "spill_first", "spill_lanes", "spill_min_mrd", "spill_min_work", "spill_cyc_shift"])}
+     "rf_livemin", "rf_patience", "rf_batch", "rf_waves", "cycle_detect", "probe_mid", "prepass_overlap", "exact_long", "scan_inline", "wave_limit", "units_min_light", "xcd_balance", "m_late", "h_settled", "classify_wg", "scan_strip", "cycle_window", "spill_first", "spill_lanes", "spill_min_mrd", "spill_min_blocks", "spill_cyc_shift"])}
 MBK_PRECISION_F32 = 0x1000
 MBK_LAZY_UNIFORM = 0x2000
 PRECISIONS = {"f64": 0, "f32": MBK_PRECISION_F32}

@@ -588,15 +588,18 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
     }
     // SPILL (round 6; mbk_kernels.h: block_pixel_spill, mbk_spill.h): the launches the units kernel does not serve -- deep zooms:
     // little light area, long orbits -- with single-wave workgroups, 16-step groups (fp64) and counts / bytes as outputs, when
-    // the depth and the size are worth a second pass (MBK_OPT_SPILL_MIN_MRD, MBK_OPT_SPILL_MIN_WORK: a fill + four small kernels
-    // ~ 30 us -- a 128-row band of cfg3 lasts 200 us) and a checkpoint fits (the per-step prologue + the first checkpoint + 64
-    // steps).  Slot numbers are 32 bits, a lane's step count 26.
+    // the depth and the size are worth a second pass and a checkpoint fits (the per-step prologue + the first checkpoint + 64 steps).
+    // The second pass lasts at least as long as ONE wave needs for the steps a never-escaping lane has left -- ~ mrd x 21 ns, a
+    // lone wave issues one dependent instruction per 8 cycles: 0.21 ms at mrd 10 000, 1.05 ms at 50 000 -- whatever the size of the
+    // launch, while what the first pass saves grows with the number of blocks: the two meet near 2^19 blocks (measured: cfg3,
+    // 2^20 blocks, +4.7 %; a 16 384 x 1 024 band of cfg4, 2^18 blocks at mrd 50 000, -4 %: profiles/r06/spill_ab.txt), hence
+    // MBK_OPT_SPILL_MIN_BLOCKS.  Slot numbers are 32 bits, a lane's step count 26.
     StreamScratch *spill_sc = nullptr;
     const uint32_t spill_first = ctx->opt[MBK_OPT_SPILL_FIRST], spill_lanes = ctx->opt[MBK_OPT_SPILL_LANES];
     const bool spill = !units && a.order != nullptr && order_mode >= 2u && kernel == MBK_KERNEL_GROUP && !safe && a.smooth == nullptr && wpw == 1u &&
                        (a.counts || a.bytes) && spill_first != 0u && (f32 || ctx->opt[MBK_OPT_GROUP_STEPS] == 16u) &&
                        (uint32_t)a.mrd >= ctx->opt[MBK_OPT_SPILL_MIN_MRD] && (uint32_t)a.mrd < (1u << 26) &&
-                       ((uint64_t)grid.x * (uint32_t)a.mrd) >> ctx->opt[MBK_OPT_SPILL_MIN_WORK] != 0ull &&
+                       ((uint64_t)grid.x >> ctx->opt[MBK_OPT_SPILL_MIN_BLOCKS]) != 0ull &&
                        (uint64_t)a.mrd > (uint64_t)ctx->opt[MBK_OPT_EXACT_STEPS] + spill_first + 66u &&
                        (uint64_t)grid.x * spill_lanes < (1ull << 32) && a.fast_bx_end > 0u && a.fast_by_end > 0u;
     if (spill) {
@@ -1251,7 +1254,7 @@ int mbk_create(int device, mbk_ctx **out)
         /* RF_LIVEMIN */ 48u, /* RF_PATIENCE */ 256u, /* RF_BATCH */ 1u, /* RF_WAVES */ 8u, /* CYCLE_DETECT */ 1u,
         /* PROBE_MID */ 65537u, /* PREPASS_OVERLAP */ 1u, /* EXACT_LONG */ 0u, /* SCAN_INLINE */ 1u, /* WAVE_LIMIT */ 0u,
         /* UNITS_MIN_LIGHT */ 32768u, /* XCD_BALANCE */ 0u, /* M_LATE */ 8u, /* H_SETTLED */ 6u, /* CLASSIFY_WG */ 1024u,
-        /* SCAN_STRIP */ 1u, /* CYCLE_WINDOW */ 32u, /* SPILL_FIRST */ 256u, /* SPILL_LANES */ 16u, /* SPILL_MIN_MRD */ 2048u, /* SPILL_MIN_WORK */ 29u, /* SPILL_CYC_SHIFT */ 5u};
+        /* SCAN_STRIP */ 1u, /* CYCLE_WINDOW */ 32u, /* SPILL_FIRST */ 256u, /* SPILL_LANES */ 16u, /* SPILL_MIN_MRD */ 2048u, /* SPILL_MIN_BLOCKS */ 19u, /* SPILL_CYC_SHIFT */ 5u};
     std::memcpy(ctx->opt, kDefaults, sizeof(kDefaults));
 #define MBK_CREATE_HIP(call)                                                        \
     do {                                                                            \
@@ -1786,7 +1789,7 @@ int mbk_set_option(mbk_ctx *ctx, int option, uint32_t value)
         case MBK_OPT_SPILL_FIRST: ok = value <= 65536u && value % 32u == 0u; break;
         case MBK_OPT_SPILL_LANES: ok = value >= 1u && value <= 32u; break;
         case MBK_OPT_SPILL_MIN_MRD: ok = true; break;
-        case MBK_OPT_SPILL_MIN_WORK: ok = value <= 62u; break;
+        case MBK_OPT_SPILL_MIN_BLOCKS: ok = value <= 31u; break;
         case MBK_OPT_SPILL_CYC_SHIFT: ok = value <= 31u; break;
         default: return fail(ctx, MBK_ERR_INVALID, "unknown MBK_OPT_* selector");
     }

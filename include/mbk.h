@@ -350,10 +350,11 @@ enum mbk_option {
                               identical counts.  0 = off, else a multiple of 32 up to 65536 [256] */
     MBK_OPT_SPILL_LANES,   /* SPILL: a block spills when this many lanes or fewer are alive at a checkpoint (= the slots of 20 bytes a
                               block owns in the list: 335 MB for an 8192^2 window at 16): 1 .. 32 [16] */
-    MBK_OPT_SPILL_MIN_MRD, /* SPILL: only launches with mrd at least this deep (the second pass costs four small kernels, ~30 us,
-                              and shallow tiles have nothing to hand over): [2048] */
-    MBK_OPT_SPILL_MIN_WORK, /* SPILL: ... and only launches of at least 2^this (8x8 blocks x mrd): [29] = a 4096^2 tile at mrd 2048, 512 rows
-                              of an 8192-wide view at mrd 8192 -- launches of a millisecond and more.  0 .. 62 */
+    MBK_OPT_SPILL_MIN_MRD, /* SPILL: only launches with mrd at least this deep (shallow tiles have nothing to hand over): [2048] */
+    MBK_OPT_SPILL_MIN_BLOCKS, /* SPILL: ... and only launches of at least 2^this 8x8 blocks: [19] = 5 800^2 pixels.  The second pass cannot
+                              be shorter than one wave running the steps a never-escaping pixel has left (~ mrd x 21 ns: 0.2 ms at
+                              mrd 10 000, 1 ms at 50 000) plus four small kernels (~30 us), while the first pass' saving grows with
+                              the launch: below ~2^19 blocks the pass costs what it saves.  0 .. 31 */
     MBK_OPT_SPILL_CYC_SHIFT, /* SPILL with the cycle test: the second pass resumes orbits that have n steps behind them; the window of its
                               first reference state is n >> this checks (of 8 steps) instead of 1 -- [5]: where the schedule of an
                               unbroken run would stand (windows of ~ n / 4 steps); 31 = start at 1.  Any schedule is exact.  0 .. 31 */

@@ -17,7 +17,7 @@ OPTION_CHOICES = {"scan_waves": [1, 2, 8], "scan_xcd_map": [0, 1], "scan_col_per
                   "exact_steps": [0, 3, 8, 20], "order": [0, 1, 2, 3], "xcd_balance": [0, 1, 2], "units_min_light": [0, 32768], "heavy_share": [0, 655, 65536], "waves_per_wg": [1, 2, 4],
                   "cycle_detect": [0, 1], "probe_mid": [2, 6, 65537], "prepass_overlap": [0, 1, 2], "probe_steps": [2, 32, 200], "exact_long": [0, 4, 8],
                   "m_late": [0, 4, 8, 12], "h_settled": [0, 5, 6, 9], "classify_wg": [64, 256, 1024], "scan_strip": [0, 1], "cycle_window": [0, 6, 32, 4096],
-                  "spill_first": [0, 32, 64, 256], "spill_lanes": [1, 7, 16, 32], "spill_min_mrd": [2, 100], "spill_min_work": [0, 0, 29], "spill_cyc_shift": [0, 5, 31]}
+                  "spill_first": [0, 32, 64, 256], "spill_lanes": [1, 7, 16, 32], "spill_min_mrd": [2, 100], "spill_min_blocks": [0, 0, 19], "spill_cyc_shift": [0, 5, 31]}
 t0 = time.time(); n = 0; px = 0
 dev = None
 while time.time() - t0 < budget:

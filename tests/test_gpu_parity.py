@@ -457,8 +457,8 @@ OPTION_MATRIX = [
     ("scan", {"scan_strip": 0}), ("default", {"scan_strip": 0, "cycle_detect": 0, "scan_waves": 3}),
     ("group", {"cycle_window": 0}), ("default", {"cycle_window": 5}), ("scan", {"cycle_window": 65536, "group_steps": 8}),
     ("default", {"cycle_window": 1, "h_settled": 0, "m_late": 0}),
-    ("group", {"spill_first": 32, "spill_lanes": 32, "spill_min_mrd": 2, "spill_min_work": 0, "order": 2}), ("default", {"spill_first": 0}),
-    ("default", {"spill_first": 64, "spill_lanes": 3, "spill_min_mrd": 100, "spill_min_work": 3, "units_min_light": 65536, "cycle_detect": 0}),
+    ("group", {"spill_first": 32, "spill_lanes": 32, "spill_min_mrd": 2, "spill_min_blocks": 0, "order": 2}), ("default", {"spill_first": 0}),
+    ("default", {"spill_first": 64, "spill_lanes": 3, "spill_min_mrd": 100, "spill_min_blocks": 3, "units_min_light": 65536, "cycle_detect": 0}),
 ]
 
 
@@ -513,7 +513,7 @@ def test_spill_second_pass_is_bit_exact(oracle, precision, cycle):
         with MandelbrotDevice(0) as dev:
             dev.set_option("cycle_detect", cycle)
             dev.set_option("spill_min_mrd", 2)
-            dev.set_option("spill_min_work", 0)
+            dev.set_option("spill_min_blocks", 0)
             for name, value in opts.items():
                 dev.set_option(name, value)
             for i, (view, mrd, window, kernel, extra) in enumerate(views):
@@ -538,9 +538,9 @@ def test_spill_second_pass_is_bit_exact(oracle, precision, cycle):
         dev.compute_view(views[0][0], views[0][1], want_bytes=False, precision=precision)
         assert dev.spill_info()["launches"] == 0
     with MandelbrotDevice(0) as dev:
-        dev.compute_view(views[0][0], 4096, want_bytes=False, precision=precision)      # 2^14 blocks x 2^12 steps: under MBK_OPT_SPILL_MIN_WORK
+        dev.compute_view(views[0][0], 4096, want_bytes=False, precision=precision)      # 2^14 blocks: under MBK_OPT_SPILL_MIN_BLOCKS
         assert dev.spill_info()["launches"] == 0
-        dev.set_option("spill_min_work", 0)
+        dev.set_option("spill_min_blocks", 0)
         dev.compute_view(views[0][0], 1500, want_bytes=False, precision=precision)      # mrd below MBK_OPT_SPILL_MIN_MRD
         assert dev.spill_info()["launches"] == 0
         dev.compute_view(views[0][0], 2048, want_bytes=False, precision=precision)
