@@ -348,8 +348,8 @@ enum mbk_option {
                               their state to a list in HBM and ends; a prefix sum compacts the list (no atomics) and a second kernel
                               runs the listed lanes 64 to a wave from where they stopped.  Same recurrence from the same state:
                               identical counts.  0 = off, else a multiple of 32 up to 65536 [256] */
-    MBK_OPT_SPILL_LANES,   /* SPILL: a block spills when this many lanes or fewer are alive at a checkpoint (= the slots of 20 bytes a
-                              block owns in the list: 335 MB for an 8192^2 window at 16): 1 .. 32 [16] */
+    MBK_OPT_SPILL_LANES,   /* SPILL: a block spills when this many lanes or fewer are alive at a checkpoint (= the slots of 24 bytes a
+                              block owns: state, lane / step word, list entry -- 403 MB for an 8192^2 window at 16): 1 .. 32 [16] */
     MBK_OPT_SPILL_MIN_MRD, /* SPILL: only launches with mrd at least this deep (shallow tiles have nothing to hand over): [2048] */
     MBK_OPT_SPILL_MIN_BLOCKS, /* SPILL: ... and only launches of at least 2^this 8x8 blocks: [19] = 5 800^2 pixels.  The second pass cannot
                               be shorter than one wave running the steps a never-escaping pixel has left (~ mrd x 21 ns: 0.2 ms at
