@@ -613,23 +613,36 @@ static int launch_blocks(mbk_ctx *ctx, TileArgs a, uint32_t kernel, bool safe, b
                 *q = nullptr;
             }
             sc->spill_cap_slots = sc->spill_cap_blocks = 0;
-            MBK_HIP(ctx, hipMalloc(&sc->d_spill_z, slots * 16u));          // (zr, zi) as two doubles; two floats use half of it
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_meta, slots * sizeof(uint32_t)));
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_src, slots * sizeof(uint32_t)));
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_cnt, (size_t)grid.x * sizeof(uint32_t)));
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_chunks, (nchunks * mbk::kSpillLevels + 1u) * sizeof(uint32_t)));
-            MBK_HIP(ctx, hipMalloc((void **)&sc->d_spill_total, sizeof(unsigned long long)));
-            sc->spill_cap_slots = slots;
-            sc->spill_cap_blocks = grid.x;
+            // 24 bytes per slot (403 MB for an 8192^2 window): a device short of memory runs the launch without the second pass
+            // -- an optimisation must not turn into an error -- and the next launch that wants it tries again
+            const bool got = hipMalloc(&sc->d_spill_z, slots * 16u) == hipSuccess &&          // (zr, zi) as two doubles; two floats use half of it
+                             hipMalloc((void **)&sc->d_spill_meta, slots * sizeof(uint32_t)) == hipSuccess &&
+                             hipMalloc((void **)&sc->d_spill_src, slots * sizeof(uint32_t)) == hipSuccess &&
+                             hipMalloc((void **)&sc->d_spill_cnt, (size_t)grid.x * sizeof(uint32_t)) == hipSuccess &&
+                             hipMalloc((void **)&sc->d_spill_chunks, (nchunks * mbk::kSpillLevels + 1u) * sizeof(uint32_t)) == hipSuccess &&
+                             hipMalloc((void **)&sc->d_spill_total, sizeof(unsigned long long)) == hipSuccess;
+            if (got) {
+                sc->spill_cap_slots = slots;
+                sc->spill_cap_blocks = grid.x;
+            } else {
+                (void)hipGetLastError();   // (the failed allocation's sticky error)
+                for (void **q : {&sc->d_spill_z, (void **)&sc->d_spill_meta, (void **)&sc->d_spill_cnt, (void **)&sc->d_spill_chunks,
+                                 (void **)&sc->d_spill_src, (void **)&sc->d_spill_total}) {
+                    if (*q) (void)hipFree(*q);
+                    *q = nullptr;
+                }
+            }
         }
-        a.spill_first = spill_first;
-        a.spill_lanes = spill_lanes;
-        a.spill_win_shift = ctx->opt[MBK_OPT_SPILL_CYC_SHIFT];
-        a.spill_z = sc->d_spill_z;
-        a.spill_meta = sc->d_spill_meta;
-        a.spill_cnt = sc->d_spill_cnt;
-        MBK_HIP(ctx, hipMemsetAsync(sc->d_spill_cnt, 0, (size_t)grid.x * sizeof(uint32_t), stream));
-        spill_sc = sc;
+        if (sc->spill_cap_slots >= slots && sc->spill_cap_blocks >= grid.x && sc->d_spill_z) {
+            a.spill_first = spill_first;
+            a.spill_lanes = spill_lanes;
+            a.spill_win_shift = ctx->opt[MBK_OPT_SPILL_CYC_SHIFT];
+            a.spill_z = sc->d_spill_z;
+            a.spill_meta = sc->d_spill_meta;
+            a.spill_cnt = sc->d_spill_cnt;
+            MBK_HIP(ctx, hipMemsetAsync(sc->d_spill_cnt, 0, (size_t)grid.x * sizeof(uint32_t), stream));
+            spill_sc = sc;
+        }
     }
     // MBK_OPT_WAVE_LIMIT: unused dynamic LDS caps the resident waves per SIMD (single-wave workgroups only)
     const uint32_t lds = wpw == 1u ? ctx->wave_limit_lds[ctx->opt[MBK_OPT_WAVE_LIMIT] & 7u] : 0u;

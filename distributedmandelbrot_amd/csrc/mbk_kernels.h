@@ -292,8 +292,9 @@ __device__ __forceinline__ int32_t block_pixel(const TileArgs &p, uint32_t ucol,
 // kernel (tile_spill_kernel, mbk_spill.h) runs the listed lanes 64 to a wave from where they stopped: escape_steps_tail resumes
 // from any state, and the deferred replay keeps the grouped test cheap there (a lane that trips just leaves).  Model on the
 // exact counts (scripts/spill_model.py): cfg3 1 219.8 -> 1 106.4 + 23.3 M wave-steps (-7.4 %) with checkpoints 256, 512, ... and
-// 16 lanes.  Exact by construction: the same recurrence from the same state; the cycle test starts afresh at every checkpoint
-// (any schedule of its reference state is exact).  Interior blocks only (regular coordinates, no lane outside the window).
+// 16 lanes.  Exact by construction: the same recurrence from the same state; the cycle test keeps ONE schedule across a block's
+// stretches (escape_steps_carry) and starts afresh in the second pass (any schedule of its reference state is exact).  Interior
+// blocks only (regular coordinates, no lane outside the window).
 // The caller stores nothing for a spilled lane (the second pass does).
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct SpillPair;
@@ -326,6 +327,9 @@ __device__ __forceinline__ void block_pixel_spill(const TileArgs &p, uint32_t uc
         escape_steps_asm<true>(cr, ci, zr, zi, a, b, m, cnt, 0u, first);
         uint32_t n = first, seg = p.spill_first, level = 0u;     // wave-uniform
         bool spilled = false;
+        // the cycle test's reference state, check counter and window, carried across the stretches (escape_steps_carry)
+        T szr = zr, szi = zi;
+        uint32_t cyc_tc = 0u, cyc_win = 1u;
         // The stretches run WITHOUT the deferred replay at their ends: a lane that tripped a group test stays pending -- frozen,
         // outside every later stretch (cnt != 0) -- and ONE fix-up behind the loop serves the whole block, as in block_pixel
         // (the first build replayed at every checkpoint: up to 16 exact steps x 9 slots per stretch in which a lane escaped,
@@ -335,8 +339,17 @@ __device__ __forceinline__ void block_pixel_spill(const TileArgs &p, uint32_t uc
             // the next checkpoint -- unless fewer than 64 steps would be left behind it: then straight to the end
             const uint32_t stop = (total - n > seg + 64u) ? n + seg : total;
             if (cnt == 0) {
-                if (kGroup >= 16 && long_groups) escape_steps_tail<16, kCycle, false>(cr, ci, zr, zi, a, b, m, cnt, n, stop, p.cyc_window);
-                else escape_steps_tail<8, kCycle, false>(cr, ci, zr, zi, a, b, m, cnt, n, stop, p.cyc_window);
+                if (kCycle) {
+                    if (kGroup >= 16 && long_groups) escape_steps_carry<16>(cr, ci, zr, zi, a, b, m, cnt, n, stop, p.cyc_window, szr, szi, cyc_tc, cyc_win);
+                    else escape_steps_carry<8>(cr, ci, zr, zi, a, b, m, cnt, n, stop, p.cyc_window, szr, szi, cyc_tc, cyc_win);
+                } else {
+                    if (kGroup >= 16 && long_groups) escape_steps_tail<16, false, false>(cr, ci, zr, zi, a, b, m, cnt, n, stop);
+                    else escape_steps_tail<8, false, false>(cr, ci, zr, zi, a, b, m, cnt, n, stop);
+                }
+            }
+            if (kCycle) {   // (uniform values that came out of a divergent region: say so)
+                cyc_tc = (uint32_t)__builtin_amdgcn_readfirstlane((int)cyc_tc);
+                cyc_win = (uint32_t)__builtin_amdgcn_readfirstlane((int)cyc_win);
             }
             n = stop;
             if (n >= total) break;

@@ -309,8 +309,8 @@ enum mbk_option {
                               earlier launches on the same stream left in pinned memory (72 stores per launch; the first launch
                               on a stream is even; only launches without the cycle test, and only those that had the chip to
                               themselves, are followed: strict cfg2 +0.7..1.2 %, nothing for the library's default path with
-                              the cycle test or several tiles in flight -- which is why it is opt-in: bench.py asks for it in
-                              its strict leg and says so), 2 a fixed uneven deal (tests).  Changes when a block is computed,
+                              the cycle test or several tiles in flight -- which is why it is opt-in: bench.py times it beside its
+                              headline, as `xcd_balance_opt_in`), 2 a fixed uneven deal (tests).  Changes when a block is computed,
                               never what is stored */
     MBK_OPT_M_LATE,        /* order 3: boundary blocks (centre pixel gone within the probe's 32 steps) whose centre escapes at
                               step >= this value open the dispatch order, before the interior blocks: the ~200 of them that

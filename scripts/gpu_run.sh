@@ -66,6 +66,12 @@ PY
         python scripts/class_table.py "$OUT/$N.txt" "$OUT/${N}_pmc_by_kernel.json" | tee "$OUT/class_table_${A//,/_}.txt"
         rm -rf "$OUT"/pmc_${N}_?
       done;;
+  spillshard) # SPILL under the sharded modes (several launches in flight hide the second pass' tail): cfg3 row bands / 2x2 / 4x4 tiles with the gate at 19 (default), 16, 0
+      for rep in 1 2; do for G in 19 17 16 0; do
+        b cfg3_bands_gate${G}_$rep --workload cfg3 --shard bands --no-cpu-baseline --opt spill_min_blocks=$G
+        b cfg3_grid2_gate${G}_$rep --workload cfg3 --shard queue --grid 2 --steps 6 --no-cpu-baseline --opt spill_min_blocks=$G
+        b cfg3_grid4_gate${G}_$rep --workload cfg3 --shard queue --grid 4 --steps 3 --no-cpu-baseline --opt spill_min_blocks=$G
+      done; done;;
   anyorder) hipcc --offload-arch=gfx950 -O3 -o /tmp/anyorder profiles/microbench/anyorder.hip 2> "$OUT/build_anyorder.log" && timeout 120 /tmp/anyorder > "$OUT/anyorder.txt" 2>&1; cat "$OUT/anyorder.txt";;
   driverline) # the driver's exact command (round 6), ARG times; driverline:N[:extra bench args with commas for spaces]
       N=${ARG%%:*}; X=${ARG#*:}; [ "$X" = "$ARG" ] && X=""; for rep in $(seq 1 ${N:-1}); do
