@@ -394,6 +394,14 @@ class SmiSampler:
             pass
         return out
 
+    def close(self):
+        if self.lib is not None:
+            try:
+                self.lib.rsmi_shut_down()
+            except Exception:   # noqa: BLE001
+                pass
+            self.lib = None
+
     def trace(self, period_s=0.02):
         """Start sampling in a thread; returns stop() -> list of samples."""
         import threading
@@ -1288,6 +1296,8 @@ def main():
         dist.destroy_process_group()
     if dev is not None:
         dev.close()
+    if smi is not None:
+        smi.close()
 
 
 def queue_job_single(args, headline_value):
