@@ -72,6 +72,7 @@ PY
         b cfg3_grid2_gate${G}_$rep --workload cfg3 --shard queue --grid 2 --steps 6 --no-cpu-baseline --opt spill_min_blocks=$G
         b cfg3_grid4_gate${G}_$rep --workload cfg3 --shard queue --grid 4 --steps 3 --no-cpu-baseline --opt spill_min_blocks=$G
       done; done;;
+  execrate) hipcc --offload-arch=gfx950 -O3 -o /tmp/exec_rate profiles/microbench/exec_rate.hip 2> "$OUT/build_exec_rate.log" && timeout 120 /tmp/exec_rate > "$OUT/exec_rate.txt" 2>&1; cat "$OUT/exec_rate.txt";;
   anyorder) hipcc --offload-arch=gfx950 -O3 -o /tmp/anyorder profiles/microbench/anyorder.hip 2> "$OUT/build_anyorder.log" && timeout 120 /tmp/anyorder > "$OUT/anyorder.txt" 2>&1; cat "$OUT/anyorder.txt";;
   driverline) # the driver's exact command (round 6), ARG times; driverline:N[:extra bench args with commas for spaces]
       N=${ARG%%:*}; X=${ARG#*:}; [ "$X" = "$ARG" ] && X=""; for rep in $(seq 1 ${N:-1}); do
