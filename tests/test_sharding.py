@@ -311,6 +311,21 @@ def test_bench_json_contract_single_rank_fake():
     assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-12
 
 
+def test_bench_smi_sampler_degrades_without_the_library_or_a_gpu():
+    """bench.py's `sustained` leg and `config.versions` read board power / clock / firmware through librocm_smi64; on a box
+    where the library is missing or finds no device every method answers None / {} / [] instead of raising -- the line must
+    not depend on it (here: no GPU)."""
+    import bench
+    s = bench.SmiSampler(0)
+    assert s.sample() is None or len(s.sample()) == 3
+    assert isinstance(s.versions(), dict)
+    stop = s.trace(0.005)
+    rows = stop()
+    assert isinstance(rows, list)
+    s.close()
+    assert s.sample() is None and s.versions() == {}
+
+
 def _run_bench_two_ranks_one_gpu(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "MBK_BENCH_FAKE")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "2",
