@@ -20,6 +20,8 @@
 #   power        power / clock traces
 #   e2e          level rate, worker end to end
 #   (round 5) strip[:reps] (scripts/strip_ab.py) | fill | gaps:W:OPT+OPT | traceopt:W:OPT+OPT[:args] | extprobe | unitstrace:W,cycle,m_late,h_settled ...
+#   (round 6) driverline:N[:args] (the driver's exact command, N times, + wall time) | prevline:N (the same on the tree under .ab/prev) | burst:C ... (burst_probe.py) |
+#             anyorder | execrate | classes:W,cycle ... (units_classes.hip + PMC + class_table.py) | spillshard (SPILL's gate under the sharded modes)
 set -u
 TAG=${1:?tag}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
